@@ -223,6 +223,7 @@ def cli_case(name, feats, meta, recipe_text, script, argv_tail, tmp, audio='synt
     rout = os.path.join(tmp, name + '.out.recipe')
     with open(rin, 'w') as f:
         f.write(recipe_text)
+    argv_tail = [a.replace('<TMP>', tmp) for a in argv_tail]
     argv = [rin, feadir + '/', '-o', rout] + list(argv_tail)
     t0 = time.time()
     status = 'ok'
@@ -237,10 +238,16 @@ def cli_case(name, feats, meta, recipe_text, script, argv_tail, tmp, audio='synt
         with open(rout) as f:
             out = f.read()
     stdout = stdout.replace(tmp, '<TMP>')
+    seg_out = None
+    for cand in (os.path.join(tmp, name + '.out-seg.recipe'),):
+        if os.path.exists(cand):
+            with open(cand) as f:
+                seg_out = f.read().replace(tmp, '<TMP>')
+    argv_tail = [a.replace(tmp, '<TMP>') for a in argv_tail]
     print('  %-28s %-24s %6.1fs  %d lines  %s' % (name, script, dt, out.count('\n'), status))
     return {'name': name, 'script': script, 'argv_tail': list(argv_tail), 'audio': audio,
             'session': meta, 'input_recipe': recipe_text, 'output_recipe': out,
-            'stdout': stdout, 'status': status, 'ref_seconds': round(dt, 2)}
+            'seg_recipe': seg_out, 'stdout': stdout, 'status': status, 'ref_seconds': round(dt, 2)}
 
 
 DIA2_CD = ['-m', 'gw', '-d', 'BIC', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0']
@@ -267,7 +274,7 @@ def pipeline_cases(tmp):
     cases.append(cli_case('A_cd_sw_bic_crash', fa, ma, vad_a, 'spk-change-detection.py',
                           ['-m', 'sw', '-d', 'BIC'], tmp))
     cases.append(cli_case('A_cd_gw_bic_dlr_seg', fa, ma, vad_a, 'spk-change-detection.py',
-                          DIA2_CD + ['-dlr', '-seg', tmp + '/'], tmp))
+                          DIA2_CD + ['-dlr', '-seg', '<TMP>/'], tmp))
     cases.append(cli_case('A_cd_m_bic', fa, ma, spkc_a, 'spk-change-detection.py', ['-m', 'm', '-d', 'BIC', '-l', '1.3'], tmp))
     cases.append(cli_case('A_cd_m_glr', fa, ma, spkc_a, 'spk-change-detection.py', ['-m', 'm', '-d', 'GLR', '-t', '1500'], tmp))
     cases.append(cli_case('A_cd_m_kl2', fa, ma, spkc_a, 'spk-change-detection.py', ['-m', 'm', '-d', 'KL2', '-t', '30'], tmp))
@@ -281,6 +288,8 @@ def pipeline_cases(tmp):
     cases.append(cli_case('A_cl1_hi_bic_ms2', fa, ma, spkc_a, 'spk-clustering.py', DIA2_CL + ['-ms', '2'], tmp))
     cases.append(cli_case('A_cl2_hi_bic_ms2', fa, ma, spkc_a, 'spk-clustering2.py', DIA2_CL + ['-ms', '2'], tmp))
     cases.append(cli_case('A_cl1_hi_bic_l3_dlr', fa, ma, spkc_a, 'spk-clustering.py', ['-m', 'hi', '-l', '3.0', '-dlr'], tmp))
+    cases.append(cli_case('A_cl1_hi_bic_seg', fa, ma, spkc_a, 'spk-clustering.py', DIA2_CL + ['-seg', '<TMP>'], tmp))
+    cases.append(cli_case('A_cl2_hi_bic_seg', fa, ma, spkc_a, 'spk-clustering2.py', DIA2_CL + ['-seg', '<TMP>/'], tmp))
     # --- session B: 420 s, 4 speakers (more merges, longer clusters)
     tmpb = os.path.join(tmp, 'B'); os.makedirs(tmpb)
     fb, vb, tb, mb = session_meta(9090, 420, 4)

@@ -1,0 +1,59 @@
+"""Pins the CPU oracle (oracle/numpy_engine.py) and the host drivers against the
+golden vectors produced by the reference scripts themselves."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, load_cases, run_case, session, assert_stdout_close
+from oracle import numpy_engine as ne
+
+CASES = load_cases()
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_cli_case_matches_reference(case, tmp_path):
+    status, stdout, recipe, seg = run_case(case, tmp_path, ne.NumpyEngine())
+    assert status == case['status']
+    assert recipe == case['output_recipe']          # byte for byte
+    assert seg == case['seg_recipe']
+    if case['status'] == 'ok':
+        assert_stdout_close(stdout, case['stdout'])
+
+
+def test_function_level_scores():
+    with open(os.path.join(ROOT, 'tests', 'golden', 'functions.json')) as f:
+        g = json.load(f)
+    feats, _, _ = session(g['session'])
+    lam = g['lambda']
+    for p in g['pairs']:
+        x, y = feats[p['a'][0]:p['a'][1]], feats[p['b'][0]:p['b'][1]]
+        want = {k: float.fromhex(v) for k, v in p.items() if k not in ('a', 'b')}
+        got_b, got_g, got_k = ne.bic_frames(x, y, lam), ne.glr_frames(x, y), ne.kl2_frames(x, y)
+        for key, got in (('cd_bic_l1.3', got_b), ('cl_bic_l1.3', got_b), ('cl2_bic_l1.3', got_b),
+                         ('glr', got_g), ('cd_glr', got_g), ('kl2', got_k), ('cd_kl2', got_k)):
+            w = want[key]
+            if math.isnan(w):
+                assert math.isnan(got)
+            else:
+                assert got == w, (key, p['a'], p['b'], got, w)    # same library calls: exact
+
+
+def test_degenerate_inputs():
+    with open(os.path.join(ROOT, 'tests', 'golden', 'functions.json')) as f:
+        g = json.load(f)
+    feats, _, truth = session(g['session'])
+    zero = np.zeros((200, 39), dtype=np.float32)
+    const = np.ones((150, 39), dtype=np.float32)
+    speech = feats[truth[0][0]:truth[0][0] + 300]
+    arrs = {'speech_zero': (speech, zero), 'zero_zero': (zero, zero), 'const_zero': (const, zero)}
+    for rec in g['degenerate']:
+        x, y = arrs[rec['name']]
+        for key, fn in (('bic', lambda: ne.bic_frames(x, y, 1.3)), ('glr', lambda: ne.glr_frames(x, y))):
+            w = float.fromhex(rec[key]) if rec[key] not in ('ValueError',) else None
+            got = fn()
+            if w is None:
+                continue
+            assert (math.isnan(w) and math.isnan(got)) or got == w
