@@ -1,0 +1,191 @@
+/*
+ * spkd.h — C ABI of libspkd_hip.so: BIC / GLR / KL2 speaker-change detection and
+ * agglomerative clustering on Gaussian sufficient statistics, hand-written HIP
+ * for gfx950 (MI355X).
+ *
+ * The reference (JianCao92/speaker-diarization) has no FFI: its hot path is
+ * Python calling numpy.cov / scipy.linalg.det per distance.  Each entry point
+ * below names the reference function(s) whose arithmetic it replaces, so a
+ * maintainer can bind it with ctypes from the scripts of the same name (see
+ * INTEGRATION.md).  Conventions:
+ *   - plain C, caller-owned buffers, no global state, one context per
+ *     (device, stream); a context is not re-entrant, different contexts are
+ *     independent;
+ *   - pointer arguments are prefixed d_ (device memory) or h_ (host memory);
+ *   - every call returns an spkd_status; spkd_last_error() gives the text;
+ *   - all scores are IEEE binary64; frames are binary32 exactly as feacat wrote
+ *     them (spk-change-detection.py:37-41).
+ *
+ * Statistics record ("stats"): SPKD_REC = 820 doubles, the packed upper triangle
+ * (row-major, r <= c) of the augmented second-moment matrix sum([x;1][x;1]^T)
+ * of a frame set, d = 39: entry (r, c) at r*40 - r*(r-1)/2 + (c - r);
+ * (r, 39) = sum x_r, (39, 39) = frame count.  Records add component-wise under
+ * set union, which is what replaces the reference's np.concatenate + np.cov.
+ */
+#ifndef SPKD_H
+#define SPKD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPKD_ABI_VERSION 1
+#define SPKD_DIM 39
+#define SPKD_REC 820
+
+typedef enum {
+    SPKD_OK = 0,
+    SPKD_EINVAL = 1,      /* bad argument / unsupported parameter combination */
+    SPKD_EHIP = 2,        /* a HIP runtime call failed */
+    SPKD_ENONFINITE = 3,  /* a covariance was NaN/inf: the reference raises ValueError there */
+    SPKD_EOVERFLOW = 4,   /* an output / log buffer was too small; *needed is set */
+    SPKD_ENOMEM = 5
+} spkd_status;
+
+typedef enum { SPKD_BIC = 0, SPKD_GLR = 1, SPKD_KL2 = 2 } spkd_kind;
+
+typedef struct spkd_ctx spkd_ctx;
+
+int spkd_abi_version(void);
+
+/* device = HIP device ordinal; stream = a hipStream_t to launch on (e.g. the
+ * caller's torch stream) or NULL for a stream owned by the context. */
+spkd_status spkd_create(int device, void *stream, spkd_ctx **out);
+void spkd_destroy(spkd_ctx *ctx);
+const char *spkd_last_error(const spkd_ctx *ctx);
+spkd_status spkd_sync(spkd_ctx *ctx);
+
+/* Device memory helpers so a ctypes-only host can run without torch. */
+spkd_status spkd_malloc(spkd_ctx *ctx, size_t bytes, void **d_ptr);
+spkd_status spkd_free(spkd_ctx *ctx, void *d_ptr);
+spkd_status spkd_memcpy_h2d(spkd_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+spkd_status spkd_memcpy_d2h(spkd_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* Timing of the most recent launch group on the context's stream, measured with
+ * HIP events recorded on that stream (milliseconds).  which: 0 = last call total. */
+spkd_status spkd_last_kernel_ms(spkd_ctx *ctx, int which, float *ms);
+
+/* ---------------------------------------------------------------------------
+ * (1) Sufficient statistics of frame sets.
+ * Replaces get_spk_features + np.cov inputs (spk-clustering.py:46-52,88-94).
+ * A set is the concatenation of one or more frame ranges [begin, end); ranges
+ * of one set are contiguous in the arrays and set ids are non-decreasing.
+ * d_stats receives n_sets records of SPKD_REC doubles.
+ */
+spkd_status spkd_set_stats(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
+                           const int64_t *h_range_begin, const int64_t *h_range_end,
+                           const int32_t *h_range_set, int64_t n_ranges,
+                           int64_t n_sets, double *d_stats);
+
+/* ---------------------------------------------------------------------------
+ * (2) Distance terms of set pairs.
+ * Replaces the bodies of bic / glr / kl2 (spk-clustering.py:81-133,
+ * spk-change-detection.py:72-133) for callers that keep the decision on the
+ * host (merge_rec, spk_cluster_in).  For pair p the 8 doubles at h_terms[8*p]:
+ *   [0] n1  [1] n2  [2] log det S1  [3] log det S2  [4] log det S(union)
+ *   [5] log det((n1 S1 + n2 S2)/N)   (only with SPKD_WANT_GLR, else NaN)
+ *   [6] KL2 as coded in the reference (only with SPKD_WANT_KL2, else NaN)
+ *   [7] reserved
+ * S = np.cov(rowvar=0) semantics (unbiased); log det = log of the LU
+ * determinant: 0 -> -inf, negative -> NaN.
+ */
+#define SPKD_WANT_GLR 1
+#define SPKD_WANT_KL2 2
+spkd_status spkd_pair_terms(spkd_ctx *ctx, const double *d_stats,
+                            const int32_t *h_idx_a, const int32_t *h_idx_b,
+                            int64_t n_pairs, int flags, double *h_terms);
+
+/* Full symmetric n x n distance matrix of one kind from n records
+ * (the initial double loop of spk_cluster_hi, spk-clustering.py:188-200);
+ * diagonal = 2^63 (sys.maxint as a float).  d_matrix: n*n doubles. */
+spkd_status spkd_distance_matrix(spkd_ctx *ctx, int kind, double lambdac,
+                                 const double *d_stats, int64_t n, double *d_matrix);
+
+/* ---------------------------------------------------------------------------
+ * (3) Change detection.
+ */
+typedef struct {
+    int32_t kind;        /* spkd_kind */
+    int32_t trace;       /* 1: log every coarse candidate (-tt); 0: only infinite ones */
+    double lambdac;      /* BIC penalty weight (-l) */
+    double threshold;    /* -t */
+    double winsize;      /* floor(w * rate), frames */
+    double winstep;      /* floor(st * rate), frames */
+    double deltaws;      /* floor(rate * dws), frames */
+    double rate;         /* frames per second (-f) */
+} spkd_cd_params;
+
+typedef struct {         /* one logged candidate evaluation */
+    int32_t turn;
+    int32_t coarse;      /* 1 = coarse scan, 0 = fine-tune scan */
+    int64_t seq;         /* (scan index << 32) | candidate index; bit 31 set = fine-tune scan */
+    double start, i, d;
+    int64_t n1, n2;
+} spkd_cand_log;
+
+/* Growing-window detector, dist_gw (spk-change-detection.py:180-288), all turns
+ * of one feature array in one launch, one workgroup per turn.
+ * Per turn t the events land at [h_ev_off[t], h_ev_off[t+1]) of the h_win_ and
+ * h_det_ arrays; capacity per turn must be >= spkd_gw_event_capacity(len, rate).
+ *   h_n_win[t]           number of coarse scans (outer iterations)
+ *   h_win_maxd[...]      best coarse distance of each scan (NaN: none accepted)
+ *   h_win_det[...]       1 if that scan ended in a detection
+ *   h_det_start/maxi/d   one triple per detection, in order
+ *   h_final_start[t]     `start` when the loop ended (the tail line starts here)
+ * h_log may be NULL (log_cap 0); *h_log_count receives the number of records the
+ * run wanted to write (SPKD_EOVERFLOW if > log_cap).
+ */
+int64_t spkd_gw_event_capacity(int64_t turn_len, double rate);
+spkd_status spkd_gw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
+                    const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
+                    const spkd_cd_params *params, const int64_t *h_ev_off,
+                    int32_t *h_n_win, double *h_win_maxd, int32_t *h_win_det,
+                    double *h_det_start, double *h_det_maxi, double *h_det_d,
+                    double *h_final_start,
+                    spkd_cand_log *h_log, int64_t log_cap, int64_t *h_log_count);
+
+/* Sliding-window distances, the per-window part of dist_sw
+ * (spk-change-detection.py:304-312): window w of turn t compares
+ * [int(w*step), int(w*step+size)) with [int(w*step+size), int(w*step+2*size)).
+ * h_d receives the distances of turn t at [h_d_off[t], h_d_off[t+1]);
+ * the count per turn is spkd_sw_window_count(len, size, step).
+ * kind = SPKD_BIC evaluates a correct two-window BIC (the reference's own
+ * sliding-window BIC path crashes). */
+int64_t spkd_sw_window_count(int64_t turn_len, double winsize, double winstep);
+spkd_status spkd_sw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
+                    const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
+                    const spkd_cd_params *params, const int64_t *h_d_off, double *h_d);
+
+/* ---------------------------------------------------------------------------
+ * (4) Agglomerative clustering, spk_cluster_hi
+ * (variant 1: spk-clustering.py:178-240, variant 2: spk-clustering2.py:173-222).
+ * n_problems independent problems (files); problem p owns the records
+ * [h_seg_off[p], h_seg_off[p+1]) of d_stats (read only).  Per problem:
+ *   h_n_merges[p]; merge m of problem p at index h_seg_off[p] + m of
+ *   h_merge_a / h_merge_b (compacted indices at the time of the merge, a < b)
+ *   and h_merge_d (the minimum that triggered it);
+ *   h_stat_max[p], h_stat_min[p]: variant 1 = running max / min over every
+ *   finite distance evaluated (NaN when never updated from the reference's
+ *   initial 0 / maxint); variant 2 = max / min of the final matrix.
+ */
+typedef struct {
+    int32_t variant;     /* 1 or 2 */
+    int32_t kind;        /* spkd_kind */
+    int32_t max_spk;     /* -ms */
+    int32_t reserved;
+    double lambdac;
+    double threshold;
+} spkd_ahc_params;
+
+spkd_status spkd_ahc(spkd_ctx *ctx, const double *d_stats, const int64_t *h_seg_off,
+                     int64_t n_problems, const spkd_ahc_params *params,
+                     int32_t *h_n_merges, int32_t *h_merge_a, int32_t *h_merge_b,
+                     double *h_merge_d, double *h_stat_max, double *h_stat_min);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPKD_H */

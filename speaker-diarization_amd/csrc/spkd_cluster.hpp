@@ -1,0 +1,491 @@
+// Pair distances and agglomerative clustering on packed statistics records.
+//
+//   k_pair_terms   : one wave per (set A, set B) job -> n, log det terms, KL2
+//                    (bodies of bic/glr/kl2: spk-clustering.py:81-133,
+//                    spk-change-detection.py:72-133)
+//   k_cluster_prep : per record, log det S and the KL2 vectors
+//   k_matrix       : initial N x N distance matrix of spk_cluster_hi
+//                    (spk-clustering.py:188-200, spk-clustering2.py:178-184)
+//   k_ahc          : the merge loop (spk-clustering.py:201-240,
+//                    spk-clustering2.py:185-222), one workgroup per problem,
+//                    device resident: arg-min with numpy semantics, statistics
+//                    merge, row recompute, v1 / v2 matrix update rules.
+//
+// Per evaluated pair the algorithmic traffic is two records in, one double out
+// = 13 128 B; one factorisation per pair (the union), because
+// the per-cluster log det terms are cached.
+#pragma once
+#include "spkd_device.hpp"
+#include "../../include/spkd.h"
+
+namespace spkd {
+
+constexpr double MAXINT_F = 9223372036854775808.0;     // float(sys.maxint) = 2^63
+constexpr double PEN_UNIT = 39.0 + 0.5 * 39.0 * 40.0;  // p + 0.5 p (p + 1), p = 39
+constexpr int AUX = 3 * DA;                            // diag S | diag pinv S | mean (as f32 value)
+constexpr int ERR_DEGENERATE_MERGE = 2;
+
+__device__ __forceinline__ unsigned long long dkey(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ bool stat_valid(double d) {       // "d != inf and d != -inf", NaN never updates
+    return d == d && fabs(d) < __builtin_huge_val();
+}
+
+// KL2 "as coded" (elementwise products, only diagonals contribute; means rounded
+// to float32 like np.mean of float32 frames): spk-clustering.py:124-133.
+__device__ __forceinline__ double kl2_combine(double s1, double p1, double m1,
+                                              double s2, double p2, double m2);
+__device__ __forceinline__ double kl2_from_aux(const double* __restrict__ a1,
+                                               const double* __restrict__ a2) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;
+    return kl2_combine(a1[i], a1[DA + i], a1[2 * DA + i], a2[i], a2[DA + i], a2[2 * DA + i]);
+}
+
+// per-lane KL2 ingredients of one record held as covariance rows in a (consumed):
+// ds = S_ii, dp = pinv(S)_ii (inverse; NaN when S is not positive definite),
+// mu = mean_i rounded to float32.
+__device__ __forceinline__ void kl2_lane_terms(double (&a)[DA], double mean_i,
+                                               double& ds, double& dp, double& mu) {
+    ds = diag_of(a);
+    const bool ok = invert_spd(a);
+    dp = diag_of(a);
+    if (!ok) dp = __builtin_nan("");
+    mu = (double)(float)mean_i;
+}
+
+__device__ __forceinline__ double kl2_combine(double s1, double p1, double m1,
+                                              double s2, double p2, double m2) {
+    const float dm = (float)m1 - (float)m2;
+    const double delta = (double)dm;
+    const double t1 = wave_sum39((s1 - s2) * (p2 - p1));
+    const double t2 = wave_sum39(((p1 + p2) * delta) * delta);
+    return 0.5 * t1 + 0.5 * t2;
+}
+
+__device__ __forceinline__ void kl2_aux_from_cov(double (&a)[DA], double mean_i,
+                                                 double* __restrict__ aux) {
+    double ds, dp, mu;
+    kl2_lane_terms(a, mean_i, ds, dp, mu);
+    const int lane = lane_id();
+    if (lane < D) {
+        aux[lane] = ds;
+        aux[DA + lane] = dp;
+        aux[2 * DA + lane] = mu;
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int PT_WAVES = 4;
+
+__global__ __launch_bounds__(PT_WAVES * WAVE) void k_pair_terms(
+        const double* __restrict__ stats, const int32_t* __restrict__ ia,
+        const int32_t* __restrict__ ib, int64_t n_pairs, int flags,
+        double* __restrict__ out, int* err) {
+    __shared__ double slabs[PT_WAVES][REC];
+    const int wave = threadIdx.x >> 6;
+    const int lane = lane_id();
+    const int64_t pair = (int64_t)blockIdx.x * PT_WAVES + wave;
+    if (pair >= n_pairs) return;
+    double* slab = slabs[wave];
+    const double* A = stats + (int64_t)ia[pair] * REC;
+    const double* B = stats + (int64_t)ib[pair] * REC;
+    const double n1 = A[REC - 1], n2 = B[REC - 1];
+    const double n = n1 + n2;
+    double res[4];
+    const int njobs = (flags & SPKD_WANT_GLR) ? 4 : 3;
+    double a[DA];
+#pragma unroll 1
+    for (int t = 0; t < njobs; ++t) {
+        auto form = [&](double (&q)[DA]) {
+            if (t < 3) {
+                if (t == 0) stage1(slab, A);
+                else if (t == 1) stage1(slab, B);
+                else stage2(slab, A, B, 1.0);
+                row_from_slab(slab, q);
+                cov_rows(q, t == 0 ? n1 : (t == 1 ? n2 : n));
+            } else {
+                // (n1/N) S1 + (n2/N) S2, linear in the moments
+                const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
+                const double be1 = al1 / n1, be2 = al2 / n2;
+                stage1(slab, A);
+                row_from_slab(slab, q);
+                const double s1i = q[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) q[j] *= al1;
+                stage1(slab, B);
+                double q2[DA];
+                row_from_slab(slab, q2);
+                const double s2i = q2[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
+                    double v = fma(al2, q2[j], q[j]);
+                    v = fma(-(be1 * s1i), s1j, v);
+                    q[j] = fma(-(be2 * s2i), s2j, v);
+                }
+            }
+        };
+        res[t] = logdet_formed(a, err, form);
+    }
+    double kl = __builtin_nan("");
+    if (flags & SPKD_WANT_KL2) {
+        double ds[2], dp[2], mu[2];
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            stage1(slab, t ? B : A);
+            row_from_slab(slab, a);
+            const double nn = t ? n2 : n1;
+            const double mean_i = a[D] / nn;
+            cov_rows(a, nn);
+            kl2_lane_terms(a, mean_i, ds[t], dp[t], mu[t]);
+        }
+        kl = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
+    }
+    if (lane == 0) {
+        double* o = out + pair * 8;
+        o[0] = n1; o[1] = n2; o[2] = res[0]; o[3] = res[1]; o[4] = res[2];
+        o[5] = (flags & SPKD_WANT_GLR) ? res[3] : __builtin_nan("");
+        o[6] = kl; o[7] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
+        const double* __restrict__ stats, int64_t n_rec, int kind,
+        double* __restrict__ ld, double* __restrict__ aux, int* err) {
+    __shared__ double slabs[PT_WAVES][REC];
+    const int wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * PT_WAVES + wave;
+    if (c >= n_rec) return;
+    double* slab = slabs[wave];
+    const double* R = stats + c * REC;
+    const double n = R[REC - 1];
+    double a[DA];
+    if (kind == SPKD_KL2) {
+        stage1(slab, R);
+        row_from_slab(slab, a);
+        const double mean_i = a[D] / n;
+        cov_rows(a, n);
+        kl2_aux_from_cov(a, mean_i, aux + c * AUX);
+        if (lane_id() == 0) ld[c] = 0.0;
+    } else {
+        auto form = [&](double (&q)[DA]) {
+            stage1(slab, R);
+            row_from_slab(slab, q);
+            cov_rows(q, n);
+        };
+        const double v = logdet_formed(a, err, form);
+        if (lane_id() == 0) ld[c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Distance between the cluster whose record is expanded in LDS (exA, count nA,
+// log det ldA) and the record C (count nC, log det ldC), staged through slab.
+// Returns the raw log det needed (union for BIC, weighted mean for GLR).
+__device__ __forceinline__ double pair_logdet(int kind, const double* exA, double nA,
+                                              const double* __restrict__ C, double nC,
+                                              double* slab, int* err) {
+    double a[DA];
+    const double n = nA + nC;
+    auto form = [&](double (&q)[DA]) {
+        stage1(slab, C);
+        row_from_expanded(exA, q);
+        if (kind == SPKD_BIC) {
+            row_acc_slab(slab, q, 1.0);
+            cov_rows(q, n);
+        } else {
+            const double al1 = (nA / n) / (nA - 1.0), al2 = (nC / n) / (nC - 1.0);
+            const double be1 = al1 / nA, be2 = al2 / nC;
+            const double s1i = q[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) q[j] *= al1;
+            row_acc_slab(slab, q, al2);
+            int li = lane_id();
+            li = li > D ? D : li;
+            const double s2i = slab[pk_off(li) - li + D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
+                double v = fma(-(be1 * s1i), s1j, q[j]);
+                q[j] = fma(-(be2 * s2i), s2j, v);
+            }
+        }
+    };
+    return logdet_formed(a, err, form);
+}
+
+__device__ __forceinline__ double finish_distance(int kind, double lambdac, double nA, double ldA,
+                                                  double nC, double ldC, double ldx) {
+    const double n = nA + nC;
+    if (kind == SPKD_BIC) {
+        double d = 0.5 * n * ldx - 0.5 * nA * ldA - 0.5 * nC * ldC;
+        d -= lambdac * 0.5 * PEN_UNIT * log(n);
+        return d;
+    }
+    return -(n / 2.0) * ((nA / n) * ldA + (nC / n) * ldC - ldx);
+}
+
+__device__ __forceinline__ int find_problem(const int64_t* __restrict__ seg_off, int64_t n_prob, int64_t g) {
+    int64_t lo = 0, hi = n_prob;            // seg_off[lo] <= g < seg_off[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return (int)lo;
+}
+
+constexpr int MX_WAVES = 8;
+
+// grid.x = total number of records; block g computes row a = g - seg_off[p] of
+// problem p: D[a][c] for c > a (and D[c][a] for variant 1), plus the diagonal /
+// lower-triangle initial values.
+__global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
+        const double* __restrict__ stats, const int64_t* __restrict__ seg_off, int64_t n_prob,
+        int variant, int kind, double lambdac,
+        const double* __restrict__ ld, const double* __restrict__ aux,
+        double* __restrict__ mat, const int64_t* __restrict__ mat_off,
+        unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
+    __shared__ double exA[DA * DA];
+    __shared__ double slabs[MX_WAVES][REC];
+    const int64_t g = blockIdx.x;
+    const int p = find_problem(seg_off, n_prob, g);
+    const int64_t off = seg_off[p];
+    const int64_t N = seg_off[p + 1] - off;
+    const int64_t ra = g - off;
+    double* Dm = mat + mat_off[p];
+    const double* A = stats + g * REC;
+    expand_to_lds(exA, A, threadIdx.x, MX_WAVES * WAVE);
+    // initial values of the cells this row owns and never computes
+    if (variant == 1) {
+        if (threadIdx.x == 0) Dm[ra * N + ra] = MAXINT_F;
+    } else {
+        for (int64_t c = threadIdx.x; c <= ra; c += MX_WAVES * WAVE) Dm[ra * N + c] = __builtin_huge_val();
+    }
+    __syncthreads();
+    const double nA = A[REC - 1];
+    const double ldA = ld[g];
+    const int wave = threadIdx.x >> 6;
+    double wmax = __builtin_nan(""), wmin = __builtin_nan("");
+    for (int64_t rc = ra + 1 + wave; rc < N; rc += MX_WAVES) {
+        const double* C = stats + (off + rc) * REC;
+        double d;
+        if (kind == SPKD_KL2) {
+            d = kl2_from_aux(aux + g * AUX, aux + (off + rc) * AUX);
+        } else {
+            const double nC = C[REC - 1];
+            const double ldx = pair_logdet(kind, exA, nA, C, nC, slabs[wave], err);
+            d = finish_distance(kind, lambdac, nA, ldA, nC, ld[off + rc], ldx);
+        }
+        if (lane_id() == 0) {
+            Dm[ra * N + rc] = d;
+            if (variant == 1) Dm[rc * N + ra] = d;
+        }
+        if (stat_valid(d)) {
+            wmax = (wmax != wmax || d > wmax) ? d : wmax;
+            wmin = (wmin != wmin || d < wmin) ? d : wmin;
+        }
+    }
+    if (variant == 1 && lane_id() == 0) {
+        if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
+        if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
+    }
+}
+
+// ---------------------------------------------------------------------------
+constexpr int AHC_WAVES = 16;
+constexpr int AHC_TPB = AHC_WAVES * WAVE;
+
+struct ArgMin {
+    double v;
+    long long idx;
+    long long nan_idx;
+};
+
+__device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
+    if (y.v < x.v || (y.v == x.v && y.idx < x.idx)) { x.v = y.v; x.idx = y.idx; }
+    if (y.nan_idx < x.nan_idx) x.nan_idx = y.nan_idx;
+}
+
+// One workgroup per problem.  stats is a private working copy (records are
+// summed in place as clusters merge).
+__global__ __launch_bounds__(AHC_TPB) void k_ahc(
+        double* __restrict__ stats, const int64_t* __restrict__ seg_off,
+        int variant, int kind, int max_spk, double lambdac, double threshold,
+        double* __restrict__ ld, double* __restrict__ aux,
+        double* __restrict__ mat, const int64_t* __restrict__ mat_off,
+        int32_t* __restrict__ alive, double* __restrict__ tmp,
+        int32_t* __restrict__ out_n, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
+        double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
+        double* __restrict__ final_max, double* __restrict__ final_min, int* err) {
+    extern __shared__ double lds[];
+    double* exA = lds;                                  // DA*DA
+    double* slabs = lds + DA * DA;                      // AHC_WAVES * REC
+    ArgMin* red = (ArgMin*)(slabs + AHC_WAVES * REC);   // AHC_WAVES entries
+    __shared__ ArgMin best;
+    __shared__ int s_cnt[2];
+    __shared__ double s_tmax[AHC_WAVES + 1];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int p = blockIdx.x;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    double* Dm = mat + mat_off[p];
+    int32_t* al = alive + off;
+    double* ldp = ld + off;
+    double* tp = tmp + off;
+    for (long long c = tid; c < N; c += AHC_TPB) al[c] = 1;
+    __syncthreads();
+    long long m = N;
+    int n_merges = 0;
+    const long long INF_IDX = 0x7fffffffffffffffLL;
+    double fmax = 0.0, fmin = 0.0;
+    while (true) {
+        // ---- 1. min / argmin over the alive sub-matrix, numpy semantics:
+        // first occurrence in row-major order; any NaN -> min is NaN and argmin is
+        // the first NaN.  (distances.min(), distances.argmin(): CL1:203-204)
+        ArgMin mine;
+        mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+        double tmax = -__builtin_huge_val();
+        for (long long l = tid; l < N * N; l += AHC_TPB) {
+            const long long r = l / N, c = l - r * N;
+            if (!al[r] || !al[c]) continue;
+            const double v = Dm[l];
+            if (v != v) { if (l < mine.nan_idx) mine.nan_idx = l; continue; }
+            if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+            tmax = v > tmax ? v : tmax;
+        }
+#pragma unroll
+        for (int s = 1; s < WAVE; s <<= 1) {
+            ArgMin o;
+            o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
+            argmin_merge(mine, o);
+            const double t2 = __shfl_xor(tmax, s);
+            tmax = t2 > tmax ? t2 : tmax;
+        }
+        if (lane == 0) { red[wave] = mine; s_tmax[wave] = tmax; }
+        __syncthreads();
+        if (tid == 0) {
+            ArgMin b = red[0];
+            double mx = s_tmax[0];
+            for (int w = 1; w < AHC_WAVES; ++w) { argmin_merge(b, red[w]); mx = s_tmax[w] > mx ? s_tmax[w] : mx; }
+            best = b;
+            s_tmax[AHC_WAVES] = mx;
+        }
+        __syncthreads();
+        const bool has_nan = best.nan_idx != INF_IDX;
+        const double mind = has_nan ? __builtin_nan("") : best.v;
+        const long long index = has_nan ? best.nan_idx : best.idx;
+        fmax = has_nan ? __builtin_nan("") : s_tmax[AHC_WAVES];
+        fmin = mind;
+        const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
+        if (!go) break;
+        const long long r0 = index / N, c0 = index - r0 * N;
+        if (r0 == c0) {                       // a diagonal cell won: see DESIGN.md (degenerate)
+            if (tid == 0) atomicOr(err, ERR_DEGENERATE_MERGE);
+            break;
+        }
+        const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
+        // compacted indices = number of alive slots in front
+        if (tid < 2) s_cnt[tid] = 0;
+        __syncthreads();
+        {
+            int ca = 0, cb = 0;
+            for (long long c = tid; c < sb; c += AHC_TPB) {
+                if (al[c]) { cb++; if (c < sa) ca++; }
+            }
+            if (ca) atomicAdd(&s_cnt[0], ca);
+            if (cb) atomicAdd(&s_cnt[1], cb);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int64_t o = off + n_merges;
+            out_a[o] = s_cnt[0]; out_b[o] = s_cnt[1]; out_d[o] = mind;
+            al[sb] = 0;
+        }
+        n_merges++;
+        m--;
+        // ---- 2. merge the statistics (speakers[a].extend(speakers[b]))
+        double* A = stats + (off + sa) * REC;
+        const double* B = stats + (off + sb) * REC;
+        for (int e = tid; e < REC; e += AHC_TPB) A[e] += B[e];
+        __syncthreads();
+        expand_to_lds(exA, A, tid, AHC_TPB);
+        __syncthreads();
+        const double nA = exA[D * DA + D];
+        // ---- 3. phase A: wave 0 refreshes the merged cluster's own terms while
+        // the other waves start on the log dets of the unions.
+        if (kind == SPKD_KL2) {
+            if (wave == 0) {
+                double a[DA];
+                row_from_expanded(exA, a);
+                const double mean_i = a[D] / nA;
+                cov_rows(a, nA);
+                kl2_aux_from_cov(a, mean_i, aux + (off + sa) * AUX);
+            }
+        } else {
+            // job -1 = self, jobs 0.. = alive slots other than sa
+            for (long long c = (long long)wave - 1; c < N; c += AHC_WAVES) {
+                if (c < 0) {
+                    double a[DA];
+                    auto form = [&](double (&q)[DA]) { row_from_expanded(exA, q); cov_rows(q, nA); };
+                    const double v = logdet_formed(a, err, form);
+                    if (lane == 0) ldp[sa] = v;
+                    continue;
+                }
+                if (c == sa || !al[c]) continue;
+                const double* C = stats + (off + c) * REC;
+                const double ldx = pair_logdet(kind, exA, nA, C, C[REC - 1], slabs + wave * REC, err);
+                if (lane == 0) tp[c] = ldx;
+            }
+        }
+        __syncthreads();
+        // ---- 4. phase B: finish the distances, update row (and column) sa
+        double wmax = __builtin_nan(""), wmin = __builtin_nan("");
+        if (kind == SPKD_KL2) {
+            for (long long c = wave; c < N; c += AHC_WAVES) {
+                if (c == sa || !al[c]) continue;
+                const double d = kl2_from_aux(aux + (off + sa) * AUX, aux + (off + c) * AUX);
+                if (lane == 0) {
+                    Dm[sa * N + c] = d;
+                    if (variant == 1) Dm[c * N + sa] = d;
+                }
+                if (stat_valid(d)) {
+                    wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                    wmin = (wmin != wmin || d < wmin) ? d : wmin;
+                }
+            }
+        } else {
+            const double ldA = ldp[sa];
+            for (long long c = tid; c < N; c += AHC_TPB) {
+                if (c == sa || !al[c]) continue;
+                const double nC = stats[(off + c) * REC + REC - 1];
+                const double d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
+                Dm[sa * N + c] = d;
+                if (variant == 1) Dm[c * N + sa] = d;
+                if (stat_valid(d)) {
+                    wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                    wmin = (wmin != wmin || d < wmin) ? d : wmin;
+                }
+            }
+        }
+        if (variant == 1) {
+            if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
+            if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out_n[p] = n_merges;
+        final_max[p] = fmax;
+        final_min[p] = fmin;
+    }
+}
+
+}  // namespace spkd

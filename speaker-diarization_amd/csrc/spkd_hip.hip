@@ -1,0 +1,541 @@
+// libspkd_hip.so — C ABI (include/spkd.h) over the HIP kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spkd.h"
+#include "spkd_cd.hpp"
+#include "spkd_cluster.hpp"
+#include "spkd_device.hpp"
+#include "spkd_stats.hpp"
+
+using namespace spkd;
+
+namespace {
+constexpr int N_SLOTS = 24;
+}
+
+struct spkd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int* d_err = nullptr;
+    unsigned long long* d_counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    void* slot[N_SLOTS] = {};
+    size_t slot_bytes[N_SLOTS] = {};
+};
+
+namespace {
+
+spkd_status fail(spkd_ctx* c, spkd_status s, const std::string& msg) {
+    if (c) c->err = msg;
+    return s;
+}
+
+#define HIPCHK(c, call)                                                              \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return fail((c), SPKD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// grow-only scratch buffers (no hipMalloc in the steady state)
+spkd_status scratch(spkd_ctx* c, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (c->slot_bytes[slot] < bytes) {
+        if (c->slot[slot]) HIPCHK(c, hipFree(c->slot[slot]));
+        c->slot[slot] = nullptr;
+        c->slot_bytes[slot] = 0;
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&c->slot[slot], want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&c->slot[slot], want);
+        }
+        if (e != hipSuccess) return fail(c, SPKD_ENOMEM, "scratch allocation failed");
+        c->slot_bytes[slot] = want;
+    }
+    *out = c->slot[slot];
+    return SPKD_OK;
+}
+
+template <class T>
+spkd_status upload(spkd_ctx* c, int slot, const std::vector<T>& h, T** d) {
+    void* p = nullptr;
+    spkd_status s = scratch(c, slot, h.size() * sizeof(T), &p);
+    if (s != SPKD_OK) return s;
+    if (!h.empty()) HIPCHK(c, hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *d = (T*)p;
+    return SPKD_OK;
+}
+
+spkd_status begin_call(spkd_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return SPKD_OK;
+}
+
+// records the end event, waits, folds the device error word into a status
+spkd_status end_call(spkd_ctx* c) {
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    int herr = 0;
+    HIPCHK(c, hipMemcpyAsync(&herr, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    if (herr & 4) return fail(c, SPKD_EOVERFLOW, "device scratch capacity exceeded");
+    if (herr & ERR_DEGENERATE_MERGE) return fail(c, SPKD_EINVAL, "degenerate merge: a diagonal cell was the minimum");
+    if (herr & ERR_NONFINITE) return fail(c, SPKD_ENONFINITE, "array must not contain infs or NaNs");
+    return SPKD_OK;
+}
+
+enum {
+    S_CHUNKS = 0, S_SETOFF, S_PARTIAL, S_IDXA, S_IDXB, S_TERMS, S_TURNS, S_SNAP, S_CAND,
+    S_EV_I32A, S_EV_I32B, S_EV_D0, S_EV_D1, S_EV_D2, S_EV_D3, S_EV_D4, S_LOG,
+    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF
+};
+
+}  // namespace
+
+extern "C" {
+
+int spkd_abi_version(void) { return SPKD_ABI_VERSION; }
+
+spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
+    if (!out) return SPKD_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SPKD_EHIP;
+    spkd_ctx* c = new spkd_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return SPKD_EHIP; }
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SPKD_EHIP; }
+        c->own_stream = true;
+    }
+    if (hipMalloc(&c->d_err, sizeof(int)) != hipSuccess ||
+        hipMalloc(&c->d_counter, sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        spkd_destroy(c);
+        return SPKD_EHIP;
+    }
+    // kernels that need more than 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)k_ahc, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)((DA * DA + AHC_WAVES * REC) * sizeof(double) + AHC_WAVES * sizeof(ArgMin)));
+    (void)hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)(GW_LDS_DOUBLES * sizeof(double)));
+    *out = c;
+    return SPKD_OK;
+}
+
+void spkd_destroy(spkd_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < N_SLOTS; ++i)
+        if (c->slot[i]) (void)hipFree(c->slot[i]);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* spkd_last_error(const spkd_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+spkd_status spkd_sync(spkd_ctx* c) {
+    if (!c) return SPKD_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPKD_OK;
+}
+
+spkd_status spkd_malloc(spkd_ctx* c, size_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) return SPKD_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(c, SPKD_ENOMEM, hipGetErrorString(e));
+    return SPKD_OK;
+}
+
+spkd_status spkd_free(spkd_ctx* c, void* d_ptr) {
+    if (!c) return SPKD_EINVAL;
+    HIPCHK(c, hipFree(d_ptr));
+    return SPKD_OK;
+}
+
+spkd_status spkd_memcpy_h2d(spkd_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    if (!c) return SPKD_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPKD_OK;
+}
+
+spkd_status spkd_memcpy_d2h(spkd_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    if (!c) return SPKD_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPKD_OK;
+}
+
+spkd_status spkd_last_kernel_ms(spkd_ctx* c, int which, float* ms) {
+    if (!c || !ms || which != 0) return SPKD_EINVAL;
+    *ms = c->last_ms;
+    return SPKD_OK;
+}
+
+// ------------------------------------------------------------------ (1) stats
+spkd_status spkd_set_stats(spkd_ctx* c, const float* d_frames, int64_t n_frames,
+                           const int64_t* h_begin, const int64_t* h_end, const int32_t* h_set,
+                           int64_t n_ranges, int64_t n_sets, double* d_stats) {
+    if (!c || !d_stats || n_sets < 0 || n_ranges < 0) return SPKD_EINVAL;
+    if (n_sets == 0) return SPKD_OK;
+    if (n_ranges > 0 && (!h_begin || !h_end || !h_set || !d_frames)) return fail(c, SPKD_EINVAL, "null range arrays");
+    std::vector<Chunk> chunks;
+    std::vector<int64_t> set_off((size_t)n_sets + 1, 0);
+    int32_t prev = 0;
+    for (int64_t r = 0; r < n_ranges; ++r) {
+        const int64_t b = h_begin[r], e = h_end[r];
+        const int32_t s = h_set[r];
+        if (b < 0 || e < b || e > n_frames || s < prev || s >= n_sets)
+            return fail(c, SPKD_EINVAL, "bad frame range or set id");
+        prev = s;
+        for (int64_t t = b; t < e; t += STATS_CHUNK) {
+            Chunk ch;
+            ch.begin = t;
+            ch.len = (int32_t)std::min<int64_t>(STATS_CHUNK, e - t);
+            ch.set = s;
+            chunks.push_back(ch);
+            set_off[(size_t)s + 1]++;
+        }
+    }
+    for (int64_t s = 0; s < n_sets; ++s) set_off[(size_t)s + 1] += set_off[(size_t)s];
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    Chunk* d_chunks = nullptr;
+    int64_t* d_setoff = nullptr;
+    void* d_partial = nullptr;
+    if ((st = upload(c, S_CHUNKS, chunks, &d_chunks)) != SPKD_OK) return st;
+    if ((st = upload(c, S_SETOFF, set_off, &d_setoff)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_PARTIAL, chunks.size() * REC * sizeof(double), &d_partial)) != SPKD_OK) return st;
+    if (!chunks.empty())
+        hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)chunks.size()), dim3(STATS_TPB), 0, c->stream,
+                           d_frames, d_chunks, (double*)d_partial);
+    hipLaunchKernelGGL(k_reduce_sets, dim3((unsigned)n_sets), dim3(STATS_TPB), 0, c->stream,
+                       (const double*)d_partial, d_setoff, d_stats);
+    HIPCHK(c, hipGetLastError());
+    return end_call(c);
+}
+
+// ------------------------------------------------------------------ (2) pair terms
+spkd_status spkd_pair_terms(spkd_ctx* c, const double* d_stats, const int32_t* h_a, const int32_t* h_b,
+                            int64_t n_pairs, int flags, double* h_terms) {
+    if (!c || n_pairs < 0) return SPKD_EINVAL;
+    if (n_pairs == 0) return SPKD_OK;
+    if (!d_stats || !h_a || !h_b || !h_terms) return fail(c, SPKD_EINVAL, "null argument");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    std::vector<int32_t> va(h_a, h_a + n_pairs), vb(h_b, h_b + n_pairs);
+    int32_t *d_a = nullptr, *d_b = nullptr;
+    void* d_terms = nullptr;
+    if ((st = upload(c, S_IDXA, va, &d_a)) != SPKD_OK) return st;
+    if ((st = upload(c, S_IDXB, vb, &d_b)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_TERMS, (size_t)n_pairs * 8 * sizeof(double), &d_terms)) != SPKD_OK) return st;
+    const unsigned blocks = (unsigned)((n_pairs + PT_WAVES - 1) / PT_WAVES);
+    hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
+                       d_stats, d_a, d_b, n_pairs, flags, (double*)d_terms, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_terms, d_terms, (size_t)n_pairs * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return end_call(c);
+}
+
+// ------------------------------------------------------------------ clustering internals
+namespace {
+struct AhcBuffers {
+    double* ld;
+    double* aux;
+    double* mat;
+    int64_t* seg_off;
+    int64_t* mat_off;
+    unsigned long long* smax;
+    unsigned long long* smin;
+};
+
+spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
+                        int variant, int kind, double lambdac, AhcBuffers& B, int64_t& n_total,
+                        std::vector<int64_t>& offs) {     // offs must outlive the stream work
+    n_total = h_seg_off[n_prob];
+    offs.clear();                                    // seg_off | mat_off
+    offs.insert(offs.end(), h_seg_off, h_seg_off + n_prob + 1);
+    int64_t cells = 0;
+    for (int64_t p = 0; p < n_prob; ++p) {
+        const int64_t n = h_seg_off[p + 1] - h_seg_off[p];
+        if (n < 0) return fail(c, SPKD_EINVAL, "seg_off must be non-decreasing");
+        offs.push_back(cells);
+        cells += n * n;
+    }
+    offs.push_back(cells);
+    int64_t* d_offs = nullptr;
+    spkd_status st;
+    if ((st = upload(c, S_AHC_OFF, offs, &d_offs)) != SPKD_OK) return st;
+    B.seg_off = d_offs;
+    B.mat_off = d_offs + n_prob + 1;
+    void* p = nullptr;
+    if ((st = scratch(c, S_AHC_LD, (size_t)n_total * sizeof(double), &p)) != SPKD_OK) return st;
+    B.ld = (double*)p;
+    if ((st = scratch(c, S_AHC_AUX, (size_t)n_total * AUX * sizeof(double), &p)) != SPKD_OK) return st;
+    B.aux = (double*)p;
+    if ((st = scratch(c, S_AHC_MAT, (size_t)cells * sizeof(double), &p)) != SPKD_OK) return st;
+    B.mat = (double*)p;
+    if ((st = scratch(c, S_AHC_MISC, (size_t)n_prob * 2 * sizeof(unsigned long long), &p)) != SPKD_OK) return st;
+    B.smax = (unsigned long long*)p;
+    B.smin = B.smax + n_prob;
+    HIPCHK(c, hipMemsetAsync(B.smax, 0x00, (size_t)n_prob * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(B.smin, 0xff, (size_t)n_prob * sizeof(unsigned long long), c->stream));
+    if (n_total > 0) {
+        const unsigned blocks = (unsigned)((n_total + PT_WAVES - 1) / PT_WAVES);
+        hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
+                           d_stats, n_total, kind, B.ld, B.aux, c->d_err);
+        hipLaunchKernelGGL(k_matrix, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
+                           d_stats, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
+                           (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
+                           B.smax, B.smin, c->d_err);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SPKD_OK;
+}
+
+double key_to_double(unsigned long long k, bool is_max) {
+    if (is_max ? (k == 0ull) : (k == ~0ull)) return std::nan("");
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    std::memcpy(&v, &b, sizeof v);
+    return v;
+}
+}  // namespace
+
+spkd_status spkd_distance_matrix(spkd_ctx* c, int kind, double lambdac, const double* d_stats,
+                                 int64_t n, double* d_matrix) {
+    if (!c || n < 0 || kind < 0 || kind > 2) return SPKD_EINVAL;
+    if (n == 0) return SPKD_OK;
+    if (!d_stats || !d_matrix) return fail(c, SPKD_EINVAL, "null argument");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    const int64_t seg_off[2] = {0, n};
+    AhcBuffers B;
+    int64_t n_total = 0;
+    std::vector<int64_t> offs;
+    if ((st = ahc_prepare(c, d_stats, seg_off, 1, 1, kind, lambdac, B, n_total, offs)) != SPKD_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(d_matrix, B.mat, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return end_call(c);
+}
+
+// ------------------------------------------------------------------ (4) AHC
+spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
+                     const spkd_ahc_params* P, int32_t* h_n_merges, int32_t* h_merge_a,
+                     int32_t* h_merge_b, double* h_merge_d, double* h_stat_max, double* h_stat_min) {
+    if (!c || !P || n_prob < 0) return SPKD_EINVAL;
+    if (n_prob == 0) return SPKD_OK;
+    if (!d_stats || !h_seg_off || !h_n_merges || !h_merge_a || !h_merge_b || !h_merge_d ||
+        !h_stat_max || !h_stat_min)
+        return fail(c, SPKD_EINVAL, "null argument");
+    if ((P->variant != 1 && P->variant != 2) || P->kind < 0 || P->kind > 2)
+        return fail(c, SPKD_EINVAL, "bad variant / kind");
+    for (int64_t p = 0; p < n_prob; ++p)
+        if (h_seg_off[p + 1] - h_seg_off[p] < 1) return fail(c, SPKD_EINVAL, "empty clustering problem");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    AhcBuffers B;
+    int64_t n_total = 0;
+    // private working copy of the records (merged in place)
+    void* wp = nullptr;
+    const int64_t nt = h_seg_off[n_prob];
+    if ((st = scratch(c, S_AHC_STATS, (size_t)nt * REC * sizeof(double), &wp)) != SPKD_OK) return st;
+    double* work = (double*)wp;
+    HIPCHK(c, hipMemcpyAsync(work, d_stats, (size_t)nt * REC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    std::vector<int64_t> offs;
+    if ((st = ahc_prepare(c, work, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs)) != SPKD_OK) return st;
+    // outputs + per-slot scratch
+    void* op = nullptr;
+    const size_t out_bytes = (size_t)n_total * (2 * sizeof(int32_t) + 2 * sizeof(double) + sizeof(int32_t)) +
+                             (size_t)n_prob * (sizeof(int32_t) + 2 * sizeof(double)) + 64;
+    if ((st = scratch(c, S_AHC_OUT, out_bytes, &op)) != SPKD_OK) return st;
+    double* d_merge_d = (double*)op;
+    double* d_tmp = d_merge_d + n_total;
+    double* d_fmax = d_tmp + n_total;
+    double* d_fmin = d_fmax + n_prob;
+    int32_t* d_a = (int32_t*)(d_fmin + n_prob);
+    int32_t* d_b = d_a + n_total;
+    int32_t* d_alive = d_b + n_total;
+    int32_t* d_n = d_alive + n_total;
+    const size_t lds = (DA * DA + AHC_WAVES * REC) * sizeof(double) + AHC_WAVES * sizeof(ArgMin);
+    hipLaunchKernelGGL(k_ahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
+                       work, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
+                       P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
+                       d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned long long> kmax((size_t)n_prob), kmin((size_t)n_prob);
+    std::vector<double> fmax((size_t)n_prob), fmin((size_t)n_prob);
+    HIPCHK(c, hipMemcpyAsync(h_n_merges, d_n, (size_t)n_prob * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_merge_a, d_a, (size_t)n_total * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_merge_b, d_b, (size_t)n_total * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_merge_d, d_merge_d, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(kmax.data(), B.smax, (size_t)n_prob * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(kmin.data(), B.smin, (size_t)n_prob * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fmax.data(), d_fmax, (size_t)n_prob * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fmin.data(), d_fmin, (size_t)n_prob * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    st = end_call(c);
+    for (int64_t p = 0; p < n_prob; ++p) {
+        if (P->variant == 1) {
+            h_stat_max[p] = key_to_double(kmax[(size_t)p], true);
+            h_stat_min[p] = key_to_double(kmin[(size_t)p], false);
+        } else {
+            h_stat_max[p] = fmax[(size_t)p];
+            h_stat_min[p] = fmin[(size_t)p];
+        }
+    }
+    return st;
+}
+
+// ------------------------------------------------------------------ (3) change detection
+int64_t spkd_gw_event_capacity(int64_t turn_len, double rate) {
+    if (turn_len < 0 || !(rate >= 10.0)) return -1;
+    // every outer iteration either advances start by >= 0.4*rate or grows end by >= 0.5*rate
+    return (int64_t)((double)turn_len / (0.2 * rate)) + 8;
+}
+
+int64_t spkd_sw_window_count(int64_t turn_len, double winsize, double winstep) {
+    if (!(winstep >= 1.0) || !(winsize >= 1.0)) return -1;
+    int64_t w = 0;
+    for (double s = 0; s + 2 * winsize <= (double)turn_len; s += winstep) ++w;
+    return w;
+}
+
+namespace {
+spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const int64_t* he, int64_t n_turns,
+                        const spkd_cd_params* P, const int64_t* h_off, bool gw, std::vector<TurnDesc>& turns,
+                        int64_t& n_snap, int64_t& n_cand) {
+    n_snap = 0;
+    n_cand = 0;
+    turns.resize((size_t)n_turns);
+    for (int64_t t = 0; t < n_turns; ++t) {
+        if (hb[t] < 0 || he[t] < hb[t] || he[t] > n_frames) return fail(c, SPKD_EINVAL, "bad turn range");
+        TurnDesc& T = turns[(size_t)t];
+        T.begin = hb[t];
+        T.len = he[t] - hb[t];
+        T.snap_off = n_snap;
+        n_snap += T.len / SNAP_G + 1;
+        T.cand_off = n_cand;
+        T.cand_cap = gw ? (int64_t)((double)T.len / (P->rate / 10)) + (int64_t)(2 * (P->rate / 10)) + 16 : 0;
+        n_cand += T.cand_cap;
+        T.ev_off = h_off[t];
+        T.ev_cap = h_off[t + 1] - h_off[t];
+        if (T.ev_cap < 0) return fail(c, SPKD_EINVAL, "offsets must be non-decreasing");
+    }
+    return SPKD_OK;
+}
+}  // namespace
+
+spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+                    const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
+                    int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det, double* h_det_start,
+                    double* h_det_maxi, double* h_det_d, double* h_final_start, spkd_cand_log* h_log,
+                    int64_t log_cap, int64_t* h_log_count) {
+    if (!c || !P || n_turns < 0) return SPKD_EINVAL;
+    if (h_log_count) *h_log_count = 0;
+    if (n_turns == 0) return SPKD_OK;
+    if (!d_frames || !hb || !he || !h_ev_off || !h_n_win || !h_win_maxd || !h_win_det || !h_det_start ||
+        !h_det_maxi || !h_det_d || !h_final_start)
+        return fail(c, SPKD_EINVAL, "null argument");
+    if (P->kind != SPKD_BIC && P->kind != SPKD_GLR) return fail(c, SPKD_EINVAL, "gw: kind must be BIC or GLR");
+    if (!(P->rate >= 10.0) || !(P->winsize >= 1.0)) return fail(c, SPKD_EINVAL, "gw: rate >= 10 and winsize >= 1 frame required");
+    std::vector<TurnDesc> turns;
+    int64_t n_snap, n_cand;
+    spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_ev_off, true, turns, n_snap, n_cand);
+    if (st != SPKD_OK) return st;
+    for (int64_t t = 0; t < n_turns; ++t)
+        if (turns[(size_t)t].ev_cap < spkd_gw_event_capacity(turns[(size_t)t].len, P->rate))
+            return fail(c, SPKD_EINVAL, "gw: event capacity too small, see spkd_gw_event_capacity");
+    if ((st = begin_call(c)) != SPKD_OK) return st;
+    const int64_t n_ev = h_ev_off[n_turns];
+    TurnDesc* d_turns = nullptr;
+    void *d_snap, *d_cand, *d_i32a, *d_i32b, *d_d0, *d_d1, *d_d2, *d_d3, *d_d4, *d_log;
+    if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_SNAP, (size_t)n_snap * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_CAND, (size_t)n_cand * 3 * sizeof(double), &d_cand)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_I32A, (size_t)n_turns * sizeof(int32_t), &d_i32a)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_I32B, (size_t)n_ev * sizeof(int32_t), &d_i32b)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_D0, (size_t)n_ev * sizeof(double), &d_d0)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_D1, (size_t)n_ev * sizeof(double), &d_d1)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_D2, (size_t)n_ev * sizeof(double), &d_d2)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_D3, (size_t)n_ev * sizeof(double), &d_d3)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_D4, (size_t)n_turns * sizeof(double), &d_d4)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_LOG, (size_t)std::max<int64_t>(log_cap, 1) * sizeof(spkd_cand_log), &d_log)) != SPKD_OK) return st;
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_DOUBLES * sizeof(double), c->stream,
+                       d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
+                       (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
+                       (double*)d_d3, (double*)d_d4, (spkd_cand_log*)d_log, (long long)log_cap,
+                       c->d_counter, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(h_n_win, d_i32a, (size_t)n_turns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_win_maxd, d_d0, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_win_det, d_i32b, (size_t)n_ev * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_det_start, d_d1, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_det_maxi, d_d2, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_det_d, d_d3, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_final_start, d_d4, (size_t)n_turns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    st = end_call(c);
+    if (h_log_count) *h_log_count = (int64_t)cnt;
+    if (h_log && log_cap > 0 && cnt > 0) {
+        const size_t ncopy = (size_t)std::min<int64_t>((int64_t)cnt, log_cap);
+        HIPCHK(c, hipMemcpy(h_log, d_log, ncopy * sizeof(spkd_cand_log), hipMemcpyDeviceToHost));
+    }
+    if (st == SPKD_OK && (int64_t)cnt > log_cap && h_log)
+        return fail(c, SPKD_EOVERFLOW, "candidate log too small");
+    return st;
+}
+
+spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+                    const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_d_off,
+                    double* h_d) {
+    if (!c || !P || n_turns < 0) return SPKD_EINVAL;
+    if (n_turns == 0) return SPKD_OK;
+    if (!d_frames || !hb || !he || !h_d_off || !h_d) return fail(c, SPKD_EINVAL, "null argument");
+    if (P->kind < 0 || P->kind > 2) return fail(c, SPKD_EINVAL, "bad kind");
+    if (!(P->winsize >= 1.0) || !(P->winstep >= 1.0)) return fail(c, SPKD_EINVAL, "sw: window and step must be >= 1 frame");
+    std::vector<TurnDesc> turns;
+    int64_t n_snap, n_cand;
+    spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_d_off, false, turns, n_snap, n_cand);
+    if (st != SPKD_OK) return st;
+    for (int64_t t = 0; t < n_turns; ++t)
+        if (turns[(size_t)t].ev_cap != spkd_sw_window_count(turns[(size_t)t].len, P->winsize, P->winstep))
+            return fail(c, SPKD_EINVAL, "sw: offsets do not match spkd_sw_window_count");
+    if ((st = begin_call(c)) != SPKD_OK) return st;
+    const int64_t n_d = h_d_off[n_turns];
+    TurnDesc* d_turns = nullptr;
+    void *d_snap, *d_out;
+    if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_SNAP, (size_t)n_snap * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_EV_D0, (size_t)n_d * sizeof(double), &d_out)) != SPKD_OK) return st;
+    hipLaunchKernelGGL(k_sw, dim3((unsigned)n_turns), dim3(SW_TPB), 0, c->stream,
+                       d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_out, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    if (n_d > 0)
+        HIPCHK(c, hipMemcpyAsync(h_d, d_out, (size_t)n_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return end_call(c);
+}
+
+}  // extern "C"

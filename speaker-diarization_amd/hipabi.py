@@ -1,0 +1,234 @@
+"""ctypes binding of include/spkd.h (libspkd_hip.so).  No torch here: device
+memory is addressed by raw pointers (``tensor.data_ptr()`` or ``dev_alloc``)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libspkd_hip.so')
+
+SPKD_OK, SPKD_EINVAL, SPKD_EHIP, SPKD_ENONFINITE, SPKD_EOVERFLOW, SPKD_ENOMEM = range(6)
+KINDS = {'BIC': 0, 'GLR': 1, 'KL2': 2}
+WANT_GLR, WANT_KL2 = 1, 2
+REC = 820
+DIM = 39
+
+EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
+           'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
+           'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
+           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw',
+           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc']
+
+
+class CdParams(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('trace', C.c_int32), ('lambdac', C.c_double),
+                ('threshold', C.c_double), ('winsize', C.c_double), ('winstep', C.c_double),
+                ('deltaws', C.c_double), ('rate', C.c_double)]
+
+
+class CandLog(C.Structure):
+    _fields_ = [('turn', C.c_int32), ('coarse', C.c_int32), ('seq', C.c_int64),
+                ('start', C.c_double), ('i', C.c_double), ('d', C.c_double),
+                ('n1', C.c_int64), ('n2', C.c_int64)]
+
+
+class AhcParams(C.Structure):
+    _fields_ = [('variant', C.c_int32), ('kind', C.c_int32), ('max_spk', C.c_int32),
+                ('reserved', C.c_int32), ('lambdac', C.c_double), ('threshold', C.c_double)]
+
+
+class SpkdError(RuntimeError):
+    def __init__(self, status, text):
+        RuntimeError.__init__(self, 'spkd status %d: %s' % (status, text))
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libspkd_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError('HIP extension %s is not built: run `python -c "import __graft_entry__ as g; '
+                          'g.build()"` (or make -C speaker-diarization_amd/csrc)' % p)
+    lib = C.CDLL(p)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    P = C.POINTER
+    lib.spkd_abi_version.restype = C.c_int
+    lib.spkd_create.argtypes = [C.c_int, vp, P(vp)]
+    lib.spkd_destroy.argtypes = [vp]
+    lib.spkd_destroy.restype = None
+    lib.spkd_last_error.argtypes = [vp]
+    lib.spkd_last_error.restype = C.c_char_p
+    lib.spkd_sync.argtypes = [vp]
+    lib.spkd_malloc.argtypes = [vp, C.c_size_t, P(vp)]
+    lib.spkd_free.argtypes = [vp, vp]
+    lib.spkd_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.spkd_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.spkd_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
+    lib.spkd_set_stats.argtypes = [vp, vp, i64, vp, vp, vp, i64, i64, vp]
+    lib.spkd_pair_terms.argtypes = [vp, vp, vp, vp, i64, C.c_int, vp]
+    lib.spkd_distance_matrix.argtypes = [vp, C.c_int, dbl, vp, i64, vp]
+    lib.spkd_gw_event_capacity.argtypes = [i64, dbl]
+    lib.spkd_gw_event_capacity.restype = i64
+    lib.spkd_gw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp, vp, vp, vp, vp, vp, vp,
+                            vp, i64, P(i64)]
+    lib.spkd_sw_window_count.argtypes = [i64, dbl, dbl]
+    lib.spkd_sw_window_count.restype = i64
+    lib.spkd_sw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp]
+    lib.spkd_ahc.argtypes = [vp, vp, vp, i64, P(AhcParams), vp, vp, vp, vp, vp, vp]
+    if lib.spkd_abi_version() != 1:
+        raise ImportError('libspkd_hip.so ABI version mismatch')
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context(object):
+    """One (device, stream) context; owns nothing but the library's scratch."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.spkd_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != SPKD_OK:
+            raise SpkdError(st, 'spkd_create failed (no usable HIP device %d?)' % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.spkd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st, allow=()):
+        if st != SPKD_OK and st not in allow:
+            raise SpkdError(st, self.lib.spkd_last_error(self.h).decode())
+        return st
+
+    def last_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.spkd_last_kernel_ms(self.h, 0, C.byref(ms)))
+        return ms.value
+
+    # ---- device memory for torch-less hosts
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self.lib.spkd_malloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        if ptr:
+            self.check(self.lib.spkd_free(self.h, C.c_void_p(ptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.spkd_memcpy_h2d(self.h, C.c_void_p(dptr), _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags['C_CONTIGUOUS']
+        self.check(self.lib.spkd_memcpy_d2h(self.h, _ptr(arr), C.c_void_p(dptr), arr.nbytes))
+
+    # ---- (1)
+    def set_stats(self, d_frames, n_frames, begins, ends, sets, n_sets, d_stats):
+        b = np.ascontiguousarray(begins, dtype=np.int64)
+        e = np.ascontiguousarray(ends, dtype=np.int64)
+        s = np.ascontiguousarray(sets, dtype=np.int32)
+        self.check(self.lib.spkd_set_stats(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e),
+                                           _ptr(s), len(b), n_sets, C.c_void_p(d_stats)))
+
+    # ---- (2)
+    def pair_terms(self, d_stats, ia, ib, flags=0):
+        ia = np.ascontiguousarray(ia, dtype=np.int32)
+        ib = np.ascontiguousarray(ib, dtype=np.int32)
+        out = np.empty((len(ia), 8), dtype=np.float64)
+        st = self.lib.spkd_pair_terms(self.h, C.c_void_p(d_stats), _ptr(ia), _ptr(ib), len(ia),
+                                      flags, _ptr(out))
+        self.check(st, allow=(SPKD_ENONFINITE,))
+        return out, st
+
+    def distance_matrix(self, kind, lambdac, d_stats, n, d_matrix):
+        st = self.lib.spkd_distance_matrix(self.h, KINDS[kind], lambdac, C.c_void_p(d_stats), n,
+                                           C.c_void_p(d_matrix))
+        return self.check(st, allow=(SPKD_ENONFINITE,))
+
+    # ---- (3)
+    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096):
+        b = np.ascontiguousarray(begins, dtype=np.int64)
+        e = np.ascontiguousarray(ends, dtype=np.int64)
+        nt = len(b)
+        caps = [self.lib.spkd_gw_event_capacity(int(e[t] - b[t]), params.rate) for t in range(nt)]
+        if any(c < 0 for c in caps):
+            raise SpkdError(SPKD_EINVAL, 'unsupported frame rate for the growing window (needs >= 10)')
+        off = np.zeros(nt + 1, dtype=np.int64)
+        off[1:] = np.cumsum(caps)
+        nev = int(off[-1])
+        n_win = np.zeros(nt, dtype=np.int32)
+        win_maxd = np.zeros(nev, dtype=np.float64)
+        win_det = np.zeros(nev, dtype=np.int32)
+        det_start = np.zeros(nev, dtype=np.float64)
+        det_maxi = np.zeros(nev, dtype=np.float64)
+        det_d = np.zeros(nev, dtype=np.float64)
+        final_start = np.zeros(nt, dtype=np.float64)
+        while True:
+            log = (CandLog * max(log_cap, 1))()
+            cnt = C.c_int64(0)
+            st = self.lib.spkd_gw(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
+                                  C.byref(params), _ptr(off), _ptr(n_win), _ptr(win_maxd),
+                                  _ptr(win_det), _ptr(det_start), _ptr(det_maxi), _ptr(det_d),
+                                  _ptr(final_start), C.cast(log, C.c_void_p), log_cap, C.byref(cnt))
+            if st == SPKD_EOVERFLOW and cnt.value > log_cap:
+                log_cap = int(cnt.value) + 16      # the run is deterministic: retry with room
+                continue
+            self.check(st, allow=(SPKD_ENONFINITE,))
+            break
+        return dict(status=st, off=off, n_win=n_win, win_maxd=win_maxd, win_det=win_det,
+                    det_start=det_start, det_maxi=det_maxi, det_d=det_d, final_start=final_start,
+                    log=log, log_count=min(int(cnt.value), log_cap))
+
+    def sw(self, d_frames, n_frames, begins, ends, params):
+        b = np.ascontiguousarray(begins, dtype=np.int64)
+        e = np.ascontiguousarray(ends, dtype=np.int64)
+        nt = len(b)
+        cnt = [self.lib.spkd_sw_window_count(int(e[t] - b[t]), params.winsize, params.winstep)
+               for t in range(nt)]
+        if any(c < 0 for c in cnt):
+            raise SpkdError(SPKD_EINVAL, 'window size and step must be at least one frame')
+        off = np.zeros(nt + 1, dtype=np.int64)
+        off[1:] = np.cumsum(cnt)
+        d = np.zeros(int(off[-1]), dtype=np.float64)
+        st = self.lib.spkd_sw(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
+                              C.byref(params), _ptr(off), _ptr(d))
+        self.check(st, allow=(SPKD_ENONFINITE,))
+        return st, off, d
+
+    # ---- (4)
+    def ahc(self, d_stats, seg_off, params):
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+        npb = len(seg_off) - 1
+        nt = int(seg_off[-1])
+        n_merges = np.zeros(npb, dtype=np.int32)
+        ma = np.zeros(nt, dtype=np.int32)
+        mb = np.zeros(nt, dtype=np.int32)
+        md = np.zeros(nt, dtype=np.float64)
+        smax = np.zeros(npb, dtype=np.float64)
+        smin = np.zeros(npb, dtype=np.float64)
+        st = self.lib.spkd_ahc(self.h, C.c_void_p(d_stats), _ptr(seg_off), npb, C.byref(params),
+                               _ptr(n_merges), _ptr(ma), _ptr(mb), _ptr(md), _ptr(smax), _ptr(smin))
+        self.check(st, allow=(SPKD_ENONFINITE,))
+        return dict(status=st, n_merges=n_merges, a=ma, b=mb, d=md, stat_max=smax, stat_min=smin)

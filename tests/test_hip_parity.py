@@ -1,0 +1,109 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI, against (a) the golden vectors produced by the reference scripts and
+(b) the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): recipes byte-identical (integer boundaries,
+labels), scores within 1e-5 relative (fp64); the tests assert tighter bounds."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, load_cases, run_case, session, assert_stdout_close
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_cases()
+# reference modes not on the device yet (growing window with KL2)
+NOT_YET = {'A_cd_gw_kl2'}
+
+
+@pytest.fixture(scope='module')
+def eng():
+    engine = pkg('engine')
+    e = engine.HipEngine(0)
+    yield e
+    e.close()
+
+
+def _rel(a, b):
+    return abs(a - b) / max(1.0, abs(a), abs(b))
+
+
+def test_stats_records_match_direct_sums(eng):
+    feats, _, truth = session({'seed': 7001, 'seconds': 400, 'n_speakers': 4, 'kwargs': {},
+                               'sha256': json.load(open(os.path.join(ROOT, 'tests/golden/functions.json')))['session']['sha256']})
+    eng.set_features(feats)
+    sets = [[(0, 50)], [(10, 11)], [(100, 5000)], [(truth[0][0], truth[0][1]), (truth[3][0], truth[3][1])],
+            [(7, 7)], [(0, feats.shape[0])]]
+    got = eng.stats(sets)
+    for k, ranges in enumerate(sets):
+        x = np.concatenate([feats[a:b] for a, b in ranges]).astype(np.float64)
+        xa = np.concatenate([x, np.ones((x.shape[0], 1))], axis=1)
+        m = xa.T @ xa
+        want = np.concatenate([m[r, r:] for r in range(40)])
+        assert got[k, 819] == x.shape[0]
+        scale = np.maximum(1.0, np.abs(want))
+        assert np.max(np.abs(got[k] - want) / scale) < 1e-12, k
+
+
+def test_pair_terms_against_reference_functions(eng):
+    g = json.load(open(os.path.join(ROOT, 'tests/golden/functions.json')))
+    feats, _, _ = session(g['session'])
+    eng.set_features(feats)
+    cd = pkg('change_detection')
+    jobs = [([tuple(p['a'])], [tuple(p['b'])]) for p in g['pairs']]
+    terms = eng.pair_terms(jobs, want_glr=True, want_kl2=True)
+    worst = 0.0
+    for p, t in zip(g['pairs'], terms):
+        n_small = min(p['a'][1] - p['a'][0], p['b'][1] - p['b'][0])
+        want_bic = float.fromhex(p['cl_bic_l1.3'])
+        want_glr = float.fromhex(p['glr'])
+        want_kl2 = float.fromhex(p['kl2'])
+        got_bic = cd.bic_from_terms(t, g['lambda'])
+        got_glr = cd.glr_from_terms(t)
+        if n_small < 40:
+            # rank-deficient covariance: the reference's determinant is rounding noise
+            continue
+        assert _rel(got_bic, want_bic) < 1e-9, (p, got_bic, want_bic)
+        assert _rel(got_glr, want_glr) < 1e-9, (p, got_glr, want_glr)
+        assert _rel(t.kl2, want_kl2) < 1e-5, (p, t.kl2, want_kl2)
+        worst = max(worst, _rel(got_bic, want_bic), _rel(got_glr, want_glr))
+    print('worst BIC/GLR relative error vs reference: %.3g' % worst)
+
+
+def test_degenerate_inputs_follow_reference(eng):
+    g = json.load(open(os.path.join(ROOT, 'tests/golden/functions.json')))
+    feats, _, truth = session(g['session'])
+    cd = pkg('change_detection')
+    zero = np.zeros((200, 39), dtype=np.float32)
+    const = np.ones((150, 39), dtype=np.float32)
+    speech = feats[truth[0][0]:truth[0][0] + 300]
+    buf = np.concatenate([speech, zero, zero, const])
+    eng.set_features(buf)
+    rng = {'speech': (0, 300), 'zero': (300, 500), 'zero2': (500, 700), 'const': (700, 850)}
+    cases = {'speech_zero': ('speech', 'zero'), 'zero_zero': ('zero', 'zero2'), 'const_zero': ('const', 'zero')}
+    for rec in g['degenerate']:
+        a, b = cases[rec['name']]
+        t = eng.pair_terms([([rng[a]], [rng[b]])], want_glr=True)[0]
+        for key, got in (('bic', cd.bic_from_terms(t, 1.3)), ('glr', cd.glr_from_terms(t))):
+            w = float.fromhex(rec[key])
+            assert (math.isnan(w) and math.isnan(got)) or got == w, (rec['name'], key, got, w)
+    # a one-frame set has a NaN covariance: the reference dies with ValueError
+    with pytest.raises(ValueError):
+        eng.pair_terms([([(0, 1)], [(0, 300)])])
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_cli_case_matches_reference(case, tmp_path, eng):
+    if case['name'] in NOT_YET:
+        pytest.skip('mode not on the device yet')
+    status, stdout, recipe, seg = run_case(case, tmp_path, eng)
+    assert status == case['status']
+    assert recipe == case['output_recipe']          # byte for byte
+    assert seg == case['seg_recipe']
+    if case['status'] == 'ok':
+        assert_stdout_close(stdout, case['stdout'], rel=1e-8)
