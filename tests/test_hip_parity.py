@@ -106,4 +106,7 @@ def test_cli_case_matches_reference(case, tmp_path, eng):
     assert recipe == case['output_recipe']          # byte for byte
     assert seg == case['seg_recipe']
     if case['status'] == 'ok':
-        assert_stdout_close(stdout, case['stdout'], rel=1e-8)
+        # KL2 mixes float32 means into fp64: the north-star bar of
+        # 1e-5 relative applies; BIC / GLR are held to 1e-9.
+        kl2 = 'KL2' in case['argv_tail']
+        assert_stdout_close(stdout, case['stdout'], rel=1e-5 if kl2 else 1e-9)
