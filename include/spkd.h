@@ -64,8 +64,14 @@ spkd_status spkd_free(spkd_ctx *ctx, void *d_ptr);
 spkd_status spkd_memcpy_h2d(spkd_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 spkd_status spkd_memcpy_d2h(spkd_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
-/* Timing of the most recent launch group on the context's stream, measured with
- * HIP events recorded on that stream (milliseconds).  which: 0 = last call total. */
+/* Timing of the most recent call, measured with HIP events recorded on the
+ * context's stream around each kernel launch (milliseconds).
+ * which: SPKD_T_CALL = whole call; SPKD_T_<kernel> = that kernel's launch inside
+ * the most recent call that used it. */
+enum {
+    SPKD_T_CALL = 0, SPKD_T_CHUNK_STATS, SPKD_T_REDUCE_SETS, SPKD_T_PAIR_TERMS,
+    SPKD_T_CLUSTER_PREP, SPKD_T_MATRIX, SPKD_T_AHC, SPKD_T_GW, SPKD_T_SW, SPKD_N_TIMERS
+};
 spkd_status spkd_last_kernel_ms(spkd_ctx *ctx, int which, float *ms);
 
 /* ---------------------------------------------------------------------------

@@ -29,6 +29,10 @@ struct spkd_ctx {
     unsigned long long* d_counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
+    // per-kernel timers (HIP events on the launch stream), see spkd_last_kernel_ms
+    hipEvent_t ka[SPKD_N_TIMERS] = {}, kb[SPKD_N_TIMERS] = {};
+    bool kused[SPKD_N_TIMERS] = {};
+    float kms[SPKD_N_TIMERS] = {};
     void* slot[N_SLOTS] = {};
     size_t slot_bytes[N_SLOTS] = {};
 };
@@ -77,8 +81,17 @@ spkd_status upload(spkd_ctx* c, int slot, const std::vector<T>& h, T** d) {
     return SPKD_OK;
 }
 
+#define TIMED(c, idx, launch)                                   \
+    do {                                                         \
+        (void)hipEventRecord((c)->ka[idx], (c)->stream);         \
+        launch;                                                  \
+        (void)hipEventRecord((c)->kb[idx], (c)->stream);         \
+        (c)->kused[idx] = true;                                  \
+    } while (0)
+
 spkd_status begin_call(spkd_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < SPKD_N_TIMERS; ++i) c->kused[i] = false;
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return SPKD_OK;
@@ -91,6 +104,9 @@ spkd_status end_call(spkd_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(&herr, c->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    c->kms[0] = c->last_ms;
+    for (int i = 1; i < SPKD_N_TIMERS; ++i)
+        if (c->kused[i]) HIPCHK(c, hipEventElapsedTime(&c->kms[i], c->ka[i], c->kb[i]));
     if (herr & 4) return fail(c, SPKD_EOVERFLOW, "device scratch capacity exceeded");
     if (herr & ERR_DEGENERATE_MERGE) return fail(c, SPKD_EINVAL, "degenerate merge: a diagonal cell was the minimum");
     if (herr & ERR_NONFINITE) return fail(c, SPKD_ENONFINITE, "array must not contain infs or NaNs");
@@ -129,6 +145,11 @@ spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
         spkd_destroy(c);
         return SPKD_EHIP;
     }
+    for (int i = 0; i < SPKD_N_TIMERS; ++i)
+        if (hipEventCreate(&c->ka[i]) != hipSuccess || hipEventCreate(&c->kb[i]) != hipSuccess) {
+            spkd_destroy(c);
+            return SPKD_EHIP;
+        }
     // kernels that need more than 64 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void*)k_ahc, hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)((DA * DA + AHC_WAVES * REC) * sizeof(double) + AHC_WAVES * sizeof(ArgMin)));
@@ -148,6 +169,10 @@ void spkd_destroy(spkd_ctx* c) {
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < SPKD_N_TIMERS; ++i) {
+        if (c->ka[i]) (void)hipEventDestroy(c->ka[i]);
+        if (c->kb[i]) (void)hipEventDestroy(c->kb[i]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -189,8 +214,8 @@ spkd_status spkd_memcpy_d2h(spkd_ctx* c, void* h_dst, const void* d_src, size_t 
 }
 
 spkd_status spkd_last_kernel_ms(spkd_ctx* c, int which, float* ms) {
-    if (!c || !ms || which != 0) return SPKD_EINVAL;
-    *ms = c->last_ms;
+    if (!c || !ms || which < 0 || which >= SPKD_N_TIMERS) return SPKD_EINVAL;
+    *ms = c->kms[which];
     return SPKD_OK;
 }
 
@@ -229,10 +254,12 @@ spkd_status spkd_set_stats(spkd_ctx* c, const float* d_frames, int64_t n_frames,
     if ((st = upload(c, S_SETOFF, set_off, &d_setoff)) != SPKD_OK) return st;
     if ((st = scratch(c, S_PARTIAL, chunks.size() * REC * sizeof(double), &d_partial)) != SPKD_OK) return st;
     if (!chunks.empty())
-        hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)chunks.size()), dim3(STATS_TPB), 0, c->stream,
-                           d_frames, d_chunks, (double*)d_partial);
-    hipLaunchKernelGGL(k_reduce_sets, dim3((unsigned)n_sets), dim3(STATS_TPB), 0, c->stream,
-                       (const double*)d_partial, d_setoff, d_stats);
+        TIMED(c, SPKD_T_CHUNK_STATS,
+              hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)chunks.size()), dim3(STATS_TPB), 0, c->stream,
+                                 d_frames, d_chunks, (double*)d_partial));
+    TIMED(c, SPKD_T_REDUCE_SETS,
+          hipLaunchKernelGGL(k_reduce_sets, dim3((unsigned)n_sets), dim3(STATS_TPB), 0, c->stream,
+                             (const double*)d_partial, d_setoff, d_stats));
     HIPCHK(c, hipGetLastError());
     return end_call(c);
 }
@@ -252,8 +279,9 @@ spkd_status spkd_pair_terms(spkd_ctx* c, const double* d_stats, const int32_t* h
     if ((st = upload(c, S_IDXB, vb, &d_b)) != SPKD_OK) return st;
     if ((st = scratch(c, S_TERMS, (size_t)n_pairs * 8 * sizeof(double), &d_terms)) != SPKD_OK) return st;
     const unsigned blocks = (unsigned)((n_pairs + PT_WAVES - 1) / PT_WAVES);
-    hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
-                       d_stats, d_a, d_b, n_pairs, flags, (double*)d_terms, c->d_err);
+    TIMED(c, SPKD_T_PAIR_TERMS,
+          hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
+                             d_stats, d_a, d_b, n_pairs, flags, (double*)d_terms, c->d_err));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_terms, d_terms, (size_t)n_pairs * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return end_call(c);
@@ -304,12 +332,14 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     HIPCHK(c, hipMemsetAsync(B.smin, 0xff, (size_t)n_prob * sizeof(unsigned long long), c->stream));
     if (n_total > 0) {
         const unsigned blocks = (unsigned)((n_total + PT_WAVES - 1) / PT_WAVES);
-        hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
-                           d_stats, n_total, kind, B.ld, B.aux, c->d_err);
-        hipLaunchKernelGGL(k_matrix, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
-                           d_stats, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
-                           (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
-                           B.smax, B.smin, c->d_err);
+        TIMED(c, SPKD_T_CLUSTER_PREP,
+              hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
+                                 d_stats, n_total, kind, B.ld, B.aux, c->d_err));
+        TIMED(c, SPKD_T_MATRIX,
+              hipLaunchKernelGGL(k_matrix, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
+                                 d_stats, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
+                                 (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
+                                 B.smax, B.smin, c->d_err));
     }
     HIPCHK(c, hipGetLastError());
     return SPKD_OK;
@@ -379,10 +409,11 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     int32_t* d_alive = d_b + n_total;
     int32_t* d_n = d_alive + n_total;
     const size_t lds = (DA * DA + AHC_WAVES * REC) * sizeof(double) + AHC_WAVES * sizeof(ArgMin);
-    hipLaunchKernelGGL(k_ahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
-                       work, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
-                       P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
-                       d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err);
+    TIMED(c, SPKD_T_AHC,
+          hipLaunchKernelGGL(k_ahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
+                             work, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
+                             P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
+                             d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
     HIPCHK(c, hipGetLastError());
     std::vector<unsigned long long> kmax((size_t)n_prob), kmin((size_t)n_prob);
     std::vector<double> fmax((size_t)n_prob), fmin((size_t)n_prob);
@@ -482,11 +513,12 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if ((st = scratch(c, S_EV_D4, (size_t)n_turns * sizeof(double), &d_d4)) != SPKD_OK) return st;
     if ((st = scratch(c, S_LOG, (size_t)std::max<int64_t>(log_cap, 1) * sizeof(spkd_cand_log), &d_log)) != SPKD_OK) return st;
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_DOUBLES * sizeof(double), c->stream,
-                       d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
-                       (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
-                       (double*)d_d3, (double*)d_d4, (spkd_cand_log*)d_log, (long long)log_cap,
-                       c->d_counter, c->d_err);
+    TIMED(c, SPKD_T_GW,
+          hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_DOUBLES * sizeof(double), c->stream,
+                             d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
+                             (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
+                             (double*)d_d3, (double*)d_d4, (spkd_cand_log*)d_log, (long long)log_cap,
+                             c->d_counter, c->d_err));
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt = 0;
     HIPCHK(c, hipMemcpyAsync(h_n_win, d_i32a, (size_t)n_turns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -530,8 +562,9 @@ spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
     if ((st = scratch(c, S_SNAP, (size_t)n_snap * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_D0, (size_t)n_d * sizeof(double), &d_out)) != SPKD_OK) return st;
-    hipLaunchKernelGGL(k_sw, dim3((unsigned)n_turns), dim3(SW_TPB), 0, c->stream,
-                       d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_out, c->d_err);
+    TIMED(c, SPKD_T_SW,
+          hipLaunchKernelGGL(k_sw, dim3((unsigned)n_turns), dim3(SW_TPB), 0, c->stream,
+                             d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_out, c->d_err));
     HIPCHK(c, hipGetLastError());
     if (n_d > 0)
         HIPCHK(c, hipMemcpyAsync(h_d, d_out, (size_t)n_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));

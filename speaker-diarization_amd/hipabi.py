@@ -11,6 +11,8 @@ LIB_PATH = os.path.join(HERE, 'csrc', 'libspkd_hip.so')
 SPKD_OK, SPKD_EINVAL, SPKD_EHIP, SPKD_ENONFINITE, SPKD_EOVERFLOW, SPKD_ENOMEM = range(6)
 KINDS = {'BIC': 0, 'GLR': 1, 'KL2': 2}
 WANT_GLR, WANT_KL2 = 1, 2
+TIMERS = {n: i for i, n in enumerate(['call', 'chunk_stats', 'reduce_sets', 'pair_terms',
+                                        'cluster_prep', 'matrix', 'ahc', 'gw', 'sw'])}
 REC = 820
 DIM = 39
 
@@ -121,9 +123,9 @@ class Context(object):
             raise SpkdError(st, self.lib.spkd_last_error(self.h).decode())
         return st
 
-    def last_ms(self):
+    def last_ms(self, which='call'):
         ms = C.c_float()
-        self.check(self.lib.spkd_last_kernel_ms(self.h, 0, C.byref(ms)))
+        self.check(self.lib.spkd_last_kernel_ms(self.h, TIMERS[which], C.byref(ms)))
         return ms.value
 
     # ---- device memory for torch-less hosts
