@@ -14,6 +14,21 @@ CASES = load_cases()
 
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_c_oracle_cli_case_matches_reference(case, tmp_path):
+    """oracle/spkd_oracle.c (fp64 sufficient statistics) against the same goldens:
+    recipes byte for byte, printed scores to 1e-9 (KL2: 1e-5, it mixes float32
+    means into fp64)."""
+    from oracle.c_engine import COracleEngine
+    status, stdout, recipe, seg = run_case(case, tmp_path, COracleEngine())
+    assert status == case['status']
+    assert recipe == case['output_recipe']
+    assert seg == case['seg_recipe']
+    if case['status'] == 'ok':
+        kl2 = 'KL2' in case['argv_tail']
+        assert_stdout_close(stdout, case['stdout'], rel=1e-5 if kl2 else 1e-9)
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_cli_case_matches_reference(case, tmp_path):
     status, stdout, recipe, seg = run_case(case, tmp_path, ne.NumpyEngine())
     assert status == case['status']
