@@ -165,6 +165,11 @@ constexpr int GW_LDS_DOUBLES = 2 * DA * DA + GW_WAVES * REC;
 // Candidate scratch per slot k: cand[0*cap + k] = i value, [1*cap + k] = memoised
 // left term (BIC: 0.5 N1 log det S1; GLR: log det S1), [2*cap + k] = right log det
 // or finished distance.
+//
+// The kernel is one loop over "scans": a coarse scan over the candidates
+// i = minfeas, minfeas + istep, ... (CD:204-221) and, after a positive one, a
+// fine scan over single-frame steps around the maximum (CD:235-251).  Both kinds
+// share one body, so the two 39x39 elimination routines exist once in the code.
 __global__ __launch_bounds__(GW_TPB) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ snap_all, double* __restrict__ cand_all,
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int li = lane > D ? D : lane;
     const int turn = blockIdx.x;
     const TurnDesc T = turns[turn];
     const long long n = T.len;
@@ -201,37 +207,53 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
     const double istep = rate / 10;
     double ws = minfeas;
     double dws = P.deltaws;
-    long long n_memo = 0;            // candidates [0, n_memo) have their left term memoised
-    long long n_written = 0;         // c_i[0 .. n_written) hold the i sequence
-    long long C = 0;                 // candidates of the current scan
-    double cur_i = minfeas;          // next i of the sequence for this epoch
-    long long a_cur = -1;
+    long long n_memo = 0;            // coarse candidates [0, n_memo) have their left term memoised
+    long long n_written = 0;         // c_i[0 .. n_written) hold the coarse i sequence
+    long long C = 0;                 // coarse candidates of the current scan
+    double cur_i = minfeas;          // next i of the coarse sequence for this epoch
+    long long a_cur = -1, c_cur = -1;
     int nw = 0, nd = 0;
     const double fn = (double)n;
     const double pen_w = P.lambdac * 0.5 * PEN_UNIT;
+    bool fine = false;               // kind of the scan about to run
+    double maxd = 0.0, maxi = 0.0;   // running maximum (carried from the coarse into the fine scan)
+    double fine_i0 = 0.0;
+    long long F = 0;
 
-    while (end <= fn) {
-        if (nw >= T.ev_cap) { if (tid == 0) atomicOr(err, 4); break; }
-        const double lim = end - start - minfeas;
-        while (cur_i < lim) {
-            if (C >= cap) break;
-            if (C >= n_written) { if (tid == 0) c_i[C] = cur_i; n_written = C + 1; }
-            ++C;
-            cur_i += istep;
+    while (fine || end <= fn) {
+        long long base, count;
+        if (!fine) {
+            if (nw >= T.ev_cap) { if (tid == 0) atomicOr(err, 4); break; }
+            const double lim = end - start - minfeas;
+            while (cur_i < lim) {
+                if (C >= cap) break;
+                if (C >= n_written) { if (tid == 0) c_i[C] = cur_i; n_written = C + 1; }
+                ++C;
+                cur_i += istep;
+            }
+            base = 0;
+            count = C;
+        } else {
+            fine_i0 = maxi - istep;
+            const double endtune = maxi + istep;
+            F = 0;
+            for (double x = fine_i0; x < endtune; x += 1) ++F;
+            if (C + F > cap) { if (tid == 0) atomicOr(err, 4); break; }
+            base = C;                // fine-scan scratch sits behind the coarse slots
+            count = F;
         }
         const long long a = (long long)start, c = (long long)end;
         if (a != a_cur) { build_expanded(exRa, snap, fr, a, tid, GW_TPB); a_cur = a; }
-        build_expanded(exRc, snap, fr, c, tid, GW_TPB);
+        if (c != c_cur) { build_expanded(exRc, snap, fr, c, tid, GW_TPB); c_cur = c; }
         __syncthreads();
         const double N = (double)(c - a);
-        // ---- coarse scan: job -1 = pooled window (BIC), jobs 0..C-1 = candidates
-        for (long long job = (long long)wave - 1; job < C; job += GW_WAVES) {
+        // ---- jobs: -1 = pooled window (BIC, coarse scans only), 0..count-1 = split points
+        for (long long job = (long long)wave - 1; job < count; job += GW_WAVES) {
             double a_[DA];
             if (job < 0) {
-                if (kind == SPKD_BIC) {
+                if (kind == SPKD_BIC && !fine) {
                     auto form = [&](double (&q)[DA]) {
                         row_from_expanded(exRc, q);
-                        int li = lane > D ? D : lane;
 #pragma unroll
                         for (int j = 0; j < DA; ++j) q[j] -= exRa[j * DA + li];
                         cov_rows(q, N);
@@ -241,108 +263,36 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
                 }
                 continue;
             }
-            const double ik = c_i[job];
+            double ik;
+            if (!fine) {
+                ik = c_i[job];
+            } else {
+                ik = fine_i0;
+                for (long long s2 = 0; s2 < job; ++s2) ik += 1;
+            }
             const long long b = (long long)(start + ik);
             const double n1 = (double)(b - a), n2 = (double)(c - b);
             double qb[DA];
             prefix_rows(qb, slab, snap, fr, b);
-            const bool need_left = job >= n_memo;
-            double ld_right = 0.0, ld_left = 0.0, ld_w = 0.0;
-            const int li = lane > D ? D : lane;
+            const bool need_left = fine || job >= n_memo;
+            double ld_right = 0.0, ld_left = 0.0, ld_w = 0.0, dist = 0.0;
+            if (kind == SPKD_KL2) {
+                double ds[2], dp[2], mu[2];
 #pragma unroll 1
-            for (int t = 0; t < 3; ++t) {
-                if (t == 1 && !need_left) continue;
-                if (t == 2 && kind != SPKD_GLR) continue;
-                auto form = [&](double (&q)[DA]) {
-                    if (t == 0) {
+                for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                        for (int j = 0; j < DA; ++j) q[j] = exRc[j * DA + li] - qb[j];
-                        cov_rows(q, n2);
-                    } else if (t == 1) {
-#pragma unroll
-                        for (int j = 0; j < DA; ++j) q[j] = qb[j] - exRa[j * DA + li];
-                        cov_rows(q, n1);
-                    } else {
-                        const double al1 = (n1 / N) / (n1 - 1.0), al2 = (n2 / N) / (n2 - 1.0);
-                        const double be1 = al1 / n1, be2 = al2 / n2;
-                        const double s1i = qb[D] - exRa[D * DA + li];
-                        const double s2i = exRc[D * DA + li] - qb[D];
-#pragma unroll
-                        for (int j = 0; j < D; ++j) {
-                            const double q1 = qb[j] - exRa[j * DA + li];
-                            const double q2 = exRc[j * DA + li] - qb[j];
-                            const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
-                            double v = fma(al2, q2, al1 * q1);
-                            v = fma(-(be1 * s1i), s1j, v);
-                            q[j] = fma(-(be2 * s2i), s2j, v);
-                        }
-                    }
-                };
-                const double v = logdet_formed(a_, err, form);
-                if (t == 0) ld_right = v; else if (t == 1) ld_left = v; else ld_w = v;
-            }
-            if (lane == 0) {
-                if (kind == SPKD_BIC) {
-                    if (need_left) c_left[job] = 0.5 * n1 * ld_left;
-                    c_x[job] = ld_right;
-                } else {
-                    if (need_left) c_left[job] = ld_left;
-                    const double l1 = need_left ? ld_left : c_left[job];
-                    c_x[job] = -(N / 2.0) * ((n1 / N) * l1 + (n2 / N) * ld_right - ld_w);
+                    for (int j = 0; j < DA; ++j)
+                        a_[j] = t ? (exRc[j * DA + li] - qb[j]) : (qb[j] - exRa[j * DA + li]);
+                    const double nn = t ? n2 : n1;
+                    const double mean_i = a_[D] / nn;
+                    cov_rows(a_, nn);
+                    kl2_lane_terms(a_, mean_i, ds[t], dp[t], mu[t]);
                 }
-            }
-        }
-        __syncthreads();
-        // ---- finish the distances (BIC), log, arg max
-        if (kind == SPKD_BIC) {
-            const double ldS = s_ldS;
-            const double corr = pen_w * log(N);
-            for (long long k = tid; k < C; k += GW_TPB) {
-                const long long b = (long long)(start + c_i[k]);
-                const double n2 = (double)(c - b);
-                double d = 0.5 * N * ldS - c_left[k] - 0.5 * n2 * c_x[k];
-                d -= corr;
-                c_x[k] = d;
-            }
-        }
-        __syncthreads();
-        for (long long k = tid; k < C; k += GW_TPB) {
-            const double d = c_x[k];
-            if (P.trace || fabs(d) == __builtin_huge_val()) {
-                const long long b = (long long)(start + c_i[k]);
-                log_cand(clog, log_cap, log_count, turn, 1, ((long long)nw << 32) | k, start, c_i[k], d, b - a, c - b);
-            }
-        }
-        if (C > n_memo) n_memo = C;
-        BestD best = block_argmax<GW_WAVES>(c_x, C, NEG_MAXINT_M1, red);
-        const bool found = best.k >= 0;
-        double maxd = best.d;
-        double maxi = found ? c_i[best.k] : 0.0;
-        const int64_t evw = T.ev_off + nw;
-        if (tid == 0) {
-            win_maxd[evw] = found ? maxd : __builtin_nan("");
-            win_det[evw] = 0;
-        }
-        ++nw;
-        if (found && maxd > P.threshold) {
-            // ---- fine tune around maxi, one frame at a time (CD:235-251)
-            const double i0 = maxi - istep, endtune = maxi + istep;
-            long long F = 0;
-            for (double x = i0; x < endtune; x += 1) ++F;
-            double* f_x = c_x + C;           // scratch behind the coarse slots
-            double* f_i = c_i + C;
-            if (C + F > cap) { if (tid == 0) atomicOr(err, 4); break; }
-            for (long long job = wave; job < F; job += GW_WAVES) {
-                double fi = i0;
-                for (long long s = 0; s < job; ++s) fi += 1;
-                const long long b = (long long)(start + fi);
-                const double n1 = (double)(b - a), n2 = (double)(c - b);
-                double qb[DA], a_[DA];
-                prefix_rows(qb, slab, snap, fr, b);
-                double ld_right = 0.0, ld_left = 0.0, ld_w = 0.0;
-                const int li = lane > D ? D : lane;
+                dist = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
+            } else {
 #pragma unroll 1
                 for (int t = 0; t < 3; ++t) {
+                    if (t == 1 && !need_left) continue;
                     if (t == 2 && kind != SPKD_GLR) continue;
                     auto form = [&](double (&q)[DA]) {
                         if (t == 0) {
@@ -372,34 +322,87 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
                     const double v = logdet_formed(a_, err, form);
                     if (t == 0) ld_right = v; else if (t == 1) ld_left = v; else ld_w = v;
                 }
-                if (lane == 0) {
-                    double d;
-                    if (kind == SPKD_BIC) {
-                        d = 0.5 * N * s_ldS - 0.5 * n1 * ld_left - 0.5 * n2 * ld_right;
-                        d -= pen_w * log(N);
-                    } else {
-                        d = -(N / 2.0) * ((n1 / N) * ld_left + (n2 / N) * ld_right - ld_w);
-                    }
-                    f_x[job] = d;
-                    f_i[job] = fi;
-                    if (fabs(d) == __builtin_huge_val())
-                        log_cand(clog, log_cap, log_count, turn, 0, ((long long)(nw - 1) << 32) | 0x80000000LL | job, start, fi, d, b - a, c - b);
+            }
+            if (lane == 0) {
+                const long long slot = base + job;
+                if (fine) c_i[slot] = ik;
+                if (kind == SPKD_BIC) {
+                    // left term: 0.5 N1 log det S1, memoised per i inside an epoch (CD:84-90)
+                    if (need_left) c_left[slot] = 0.5 * n1 * ld_left;   // fine slots: scratch only
+                    c_x[slot] = ld_right;
+                } else if (kind == SPKD_GLR) {
+                    const double l1 = need_left ? ld_left : c_left[slot];
+                    if (need_left && !fine) c_left[slot] = l1;
+                    c_x[slot] = -(N / 2.0) * ((n1 / N) * l1 + (n2 / N) * ld_right - ld_w);
+                } else {
+                    c_x[slot] = dist;
                 }
             }
+        }
+        __syncthreads();
+        // ---- finish the distances (BIC): d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
+        if (kind == SPKD_BIC) {
+            const double ldS = s_ldS;
+            const double corr = pen_w * log(N);
+            for (long long k = tid; k < count; k += GW_TPB) {
+                const long long slot = base + k;
+                const long long b = (long long)(start + c_i[slot]);
+                const double n2 = (double)(c - b);
+                double d = 0.5 * N * ldS - c_left[slot] - 0.5 * n2 * c_x[slot];
+                d -= corr;
+                c_x[slot] = d;
+            }
             __syncthreads();
-            BestD fb = block_argmax<GW_WAVES>(f_x, F, maxd, red);
-            if (fb.k >= 0) { maxd = fb.d; maxi = f_i[fb.k]; }
-            const int64_t evd = T.ev_off + nd;
+        }
+        for (long long k = tid; k < count; k += GW_TPB) {
+            const long long slot = base + k;
+            const double d = c_x[slot];
+            if ((P.trace && !fine) || fabs(d) == __builtin_huge_val()) {
+                const long long b = (long long)(start + c_i[slot]);
+                const long long w = fine ? (long long)(nw - 1) : (long long)nw;
+                log_cand(clog, log_cap, log_count, turn, fine ? 0 : 1,
+                         (w << 32) | (fine ? 0x80000000LL : 0LL) | k, start, c_i[slot], d, b - a, c - b);
+            }
+        }
+        if (!fine) {
+            if (C > n_memo) n_memo = C;
+            BestD best = block_argmax<GW_WAVES>(c_x, C, NEG_MAXINT_M1, red);
+            const bool found = best.k >= 0;
+            maxd = best.d;
+            maxi = found ? c_i[best.k] : 0.0;
             if (tid == 0) {
-                det_start[evd] = start;
-                det_maxi[evd] = maxi;
-                det_d[evd] = maxd;
-                win_det[evw] = 1;
+                win_maxd[T.ev_off + nw] = found ? maxd : __builtin_nan("");
+                win_det[T.ev_off + nw] = 0;
+            }
+            ++nw;
+            if (found && maxd > P.threshold) {
+                fine = true;             // next scan: fine tune around maxi (CD:231-251)
+                continue;
+            }
+            // negative: enlarge the window (CD:271-284)
+            if (end + ws <= fn) {
+                end += ws;
+                if (ws < winstep) { ws += dws; dws *= 2; }
+                if (ws > winstep) ws = winstep;
+            } else if (end != fn) {
+                end = fn;
+            } else {
+                break;
+            }
+        } else {
+            BestD fb = block_argmax<GW_WAVES>(c_x + C, F, maxd, red);
+            if (fb.k >= 0) { maxd = fb.d; maxi = c_i[C + fb.k]; }
+            if (tid == 0) {
+                det_start[T.ev_off + nd] = start;
+                det_maxi[T.ev_off + nd] = maxi;
+                det_d[T.ev_off + nd] = maxd;
+                win_det[T.ev_off + nw - 1] = 1;
             }
             ++nd;
-            __syncthreads();                 // f_i / c_i reads done before the next scan rewrites them
+            __syncthreads();             // reads of the scratch slots are done
+            fine = false;
             n_memo = 0;
-            n_written = n_written < C ? n_written : C;   // fine-tune scratch overwrote slots >= C
+            n_written = n_written < C ? n_written : C;   // fine-scan scratch overwrote slots >= C
             C = 0;
             cur_i = minfeas;
             start += maxi;
@@ -407,16 +410,6 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
                 end = start + winsize * 2;
                 ws = minfeas;
                 dws = P.deltaws;
-            } else {
-                break;
-            }
-        } else {
-            if (end + ws <= fn) {
-                end += ws;
-                if (ws < winstep) { ws += dws; dws *= 2; }
-                if (ws > winstep) ws = winstep;
-            } else if (end != fn) {
-                end = fn;
             } else {
                 break;
             }

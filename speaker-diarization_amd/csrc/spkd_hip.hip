@@ -488,7 +488,7 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if (!d_frames || !hb || !he || !h_ev_off || !h_n_win || !h_win_maxd || !h_win_det || !h_det_start ||
         !h_det_maxi || !h_det_d || !h_final_start)
         return fail(c, SPKD_EINVAL, "null argument");
-    if (P->kind != SPKD_BIC && P->kind != SPKD_GLR) return fail(c, SPKD_EINVAL, "gw: kind must be BIC or GLR");
+    if (P->kind < 0 || P->kind > 2) return fail(c, SPKD_EINVAL, "gw: bad kind");
     if (!(P->rate >= 10.0) || !(P->winsize >= 1.0)) return fail(c, SPKD_EINVAL, "gw: rate >= 10 and winsize >= 1 frame required");
     std::vector<TurnDesc> turns;
     int64_t n_snap, n_cand;

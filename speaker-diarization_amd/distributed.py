@@ -1,0 +1,64 @@
+"""File-sharded multi-GPU execution: one process per GPU, no collective on the
+data path (files are independent units); the only exchange is the
+gather of the finished recipes on rank 0, done with torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+RCCL has no native gather of ragged byte strings, so the exchange is two
+all_gathers: the byte counts, then the payloads padded to the longest one
+(KB-scale messages: latency bound, one collective pair per batch)."""
+import numpy as np
+
+
+def shard(items, rank, world):
+    """Round-robin: file i goes to rank i mod world (each rank keeps the order)."""
+    return [(i, it) for i, it in enumerate(items) if i % world == rank]
+
+
+def _device_for(dist):
+    import torch
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def gather_texts(local, dist=None):
+    """local: list of (file_index, text) produced by this rank.  Returns on rank 0
+    the dict {file_index: text} of ALL ranks, on the others None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(local)
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _device_for(dist)
+    # payload: [n][(index i64, length i64)] header + concatenated utf-8
+    blobs = [t.encode('utf-8') for (_, t) in local]
+    head = np.array([[i, len(b)] for (i, _), b in zip(local, blobs)], dtype=np.int64).reshape(-1, 2)
+    payload = np.frombuffer(np.int64(len(local)).tobytes() + head.tobytes() + b''.join(blobs), dtype=np.uint8)
+    size = torch.tensor([payload.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    maxlen = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(maxlen, dtype=torch.uint8, device=dev)
+    buf[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
+    bufs = [torch.zeros(maxlen, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    if rank != 0:
+        return None
+    out = {}
+    for r in range(world):
+        raw = bufs[r].cpu().numpy().tobytes()[:int(sizes[r].item())]
+        n = int(np.frombuffer(raw[:8], dtype=np.int64)[0])
+        head = np.frombuffer(raw[8:8 + 16 * n], dtype=np.int64).reshape(n, 2)
+        pos = 8 + 16 * n
+        for i, ln in head:
+            out[int(i)] = raw[pos:pos + int(ln)].decode('utf-8')
+            pos += int(ln)
+    return out
+
+
+def recipe_text(audio, rows, lna_prefix='a'):
+    """rows: [(start_s, end_s, speaker)] -> clustering-stage recipe text
+    (writer grammar of spk-clustering.py:66-70, lna renamed a_1, a_2, ...)."""
+    from .recipe import py2_float_str
+    return ''.join('audio=%s lna=%s_%d start-time=%s end-time=%s speaker=speaker_%d\n' % (
+        audio, lna_prefix, k + 1, py2_float_str(s), py2_float_str(e), spk)
+        for k, (s, e, spk) in enumerate(rows))

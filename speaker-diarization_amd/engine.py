@@ -107,8 +107,6 @@ class HipEngine(object):
 
     # ------------------------------------------------------------- growing window
     def gw(self, turns, kind, lambdac, threshold, winsize, winstep, deltaws, rate, trace=False):
-        if kind == 'KL2':
-            raise NotImplementedError('growing window with KL2 is not on the device yet')
         p = hipabi.CdParams(hipabi.KINDS[kind], 1 if trace else 0, lambdac, threshold, winsize,
                             winstep, deltaws, rate)
         b = [t[0] for t in turns]

@@ -1,0 +1,71 @@
+"""world_size-2 gloo test (CPU) of the file sharding + recipe gather used by the
+multi-GPU path.  The per-file work is a stand-in here (the sharding and the
+exchange are what is under test); on the GPU box bench.py runs the same code
+over RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_files, q):
+    import importlib
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dmod = importlib.import_module('speaker-diarization_amd.distributed')
+    files = ['file%03d.wav' % i for i in range(n_files)]
+    mine = dmod.shard(files, rank, world)
+    local = []
+    for i, name in mine:
+        rows = [(1.0 + k, 2.5 + k, (i + k) % 3 + 1) for k in range(i % 5 + (0 if i == 3 else 1))]
+        local.append((i, dmod.recipe_text(name, rows)))
+    got = dmod.gather_texts(local, dist)
+    if rank == 0:
+        q.put(got)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_files', [0, 1, 7])
+def test_shard_and_gather_two_ranks(n_files):
+    import importlib
+    dmod = importlib.import_module('speaker-diarization_amd.distributed')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_files, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(got) == list(range(n_files))
+    for i in range(n_files):
+        rows = [(1.0 + k, 2.5 + k, (i + k) % 3 + 1) for k in range(i % 5 + (0 if i == 3 else 1))]
+        assert got[i] == dmod.recipe_text('file%03d.wav' % i, rows)
+
+
+def test_single_process_gather_is_identity():
+    import importlib
+    dmod = importlib.import_module('speaker-diarization_amd.distributed')
+    assert dmod.gather_texts([(2, 'x\n'), (0, '')]) == {2: 'x\n', 0: ''}
+    assert dmod.shard(list('abcde'), 1, 2) == [(1, 'b'), (3, 'd')]

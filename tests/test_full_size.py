@@ -1,0 +1,154 @@
+"""GPU tests at BASELINE.json's full sizes (1 h, 4 and 8 speakers): the HIP path
+against the C oracle (oracle/spkd_oracle.c, itself pinned on the reference
+goldens), plus size-independent properties (additivity of statistics, batch ==
+single file, idempotence of the in-memory pipeline vs the file-based scripts)."""
+import importlib
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+CD = ['-m', 'gw', '-d', 'BIC', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0']
+CL = ['-m', 'hi', '-l', '1.3']
+
+
+@pytest.fixture(scope='module')
+def eng():
+    e = pkg('engine').HipEngine(0)
+    yield e
+    e.close()
+
+
+def _run_scripts(tmp, engine, tag, variant=1):
+    cli = pkg('cli')
+    spkc = os.path.join(tmp, tag + '.spkc.recipe')
+    final = os.path.join(tmp, tag + '.out.recipe')
+    out1, out2 = io.StringIO(), io.StringIO()
+    cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), os.path.join(tmp, 'fea') + '/', '-o', spkc] + CD,
+                              engine=engine, stdout=out1)
+    cli.main_clustering([spkc, os.path.join(tmp, 'fea') + '/', '-o', final] + CL, variant=variant,
+                        engine=engine, stdout=out2)
+    return open(spkc).read(), open(final).read(), out1.getvalue(), out2.getvalue()
+
+
+def _merge_lines(text):
+    return [(int(a), int(b), float(d)) for a, b, d in
+            re.findall(r'Merging: (\d+) and (\d+) distance: (\S+)', text)]
+
+
+@pytest.mark.parametrize('nspk,seed', [(4, 5150), (8, 8088)])
+def test_one_hour_matches_c_oracle(tmp_path, eng, nspk, seed):
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    feats, vad, _ = synth.make_session(seed, 3600, nspk)
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'hour.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(synth.vad_recipe_text('hour.wav', vad))
+    h = _run_scripts(tmp, eng, 'hip')
+    o = _run_scripts(tmp, COracleEngine(), 'orc')
+    assert h[0] == o[0]                    # change-detection recipe: integer boundaries bit exact
+    assert h[1] == o[1]                    # speaker recipe: labels identical (numbering included)
+    mh, mo = _merge_lines(h[3]), _merge_lines(o[3])
+    assert [(a, b) for a, b, _ in mh] == [(a, b) for a, b, _ in mo]
+    worst = max(abs(x[2] - y[2]) / max(1.0, abs(y[2])) for x, y in zip(mh, mo))
+    assert worst < 1e-9, worst
+    print('%d speakers: %d turns, %d merges, worst merge-distance rel err %.2g' % (
+        nspk, h[0].count('\n'), len(mh), worst))
+
+
+def test_statistics_are_additive(eng):
+    synth = pkg('synth')
+    feats, _, _ = synth.make_session(99, 300, 3)
+    eng.set_features(feats)
+    n = feats.shape[0]
+    cuts = [0, 17, 1024, 1025, 5000, 20000, n]
+    parts = eng.stats([[(a, b)] for a, b in zip(cuts[:-1], cuts[1:])])
+    whole = eng.stats([[(0, n)]])[0]
+    one_set = eng.stats([[(a, b) for a, b in zip(cuts[:-1], cuts[1:])]])[0]
+    s = parts.sum(axis=0)
+    scale = np.maximum(1.0, np.abs(whole))
+    assert np.max(np.abs(s - whole) / scale) < 1e-13
+    assert np.max(np.abs(one_set - whole) / scale) < 1e-13
+    assert whole[819] == n
+
+
+def test_distance_matrix_is_symmetric_and_matches_pair_terms(eng):
+    synth = pkg('synth')
+    hipabi = pkg('hipabi')
+    cd = pkg('change_detection')
+    feats, _, truth = synth.make_session(123, 240, 4)
+    eng.set_features(feats)
+    segs = [(a, b) for a, b, _ in truth][:24]
+    d = eng._stats_of_sets([[s] for s in segs])
+    n = len(segs)
+    dm = eng.ctx.dev_alloc(n * n * 8)
+    try:
+        eng.ctx.distance_matrix('BIC', 1.3, d, n, dm)
+        m = np.empty((n, n))
+        eng.ctx.d2h(m, dm)
+    finally:
+        eng.ctx.dev_free(dm)
+        eng.ctx.dev_free(d)
+    assert np.array_equal(m, m.T)
+    assert np.all(np.diag(m) == 2.0 ** 63)
+    jobs = [([segs[i]], [segs[j]]) for i in range(n) for j in range(i + 1, n)]
+    terms = eng.pair_terms(jobs)
+    k = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            want = cd.bic_from_terms(terms[k], 1.3)
+            assert abs(m[i, j] - want) <= 1e-10 * max(1.0, abs(want))
+            k += 1
+
+
+def test_batch_pipeline_equals_file_based_scripts(tmp_path, eng):
+    """The in-memory batch pipeline (what bench.py times) must give, per file, the
+    recipe rows the two drop-in scripts produce through files."""
+    synth = pkg('synth')
+    pipeline = pkg('pipeline')
+    recipe = pkg('recipe')
+    sessions = [synth.make_session(31 + i, 200 + 40 * i, 3 + (i % 2)) for i in range(3)]
+    frames = np.concatenate([s[0] for s in sessions])
+    eng.set_features(frames)
+    files, off = [], 0
+    for feats, vad, _ in sessions:
+        v = [(float(recipe.py2_float_str(a / 125.0)), float(recipe.py2_float_str(b / 125.0))) for a, b in vad]
+        files.append(pipeline.BatchFile(off, feats.shape[0], v))
+        off += feats.shape[0]
+    got = pipeline.diarize_batch(eng.ctx, eng.d_frames, frames.shape[0], files)
+    e2 = pkg('engine').HipEngine(0)
+    try:
+        for k, (feats, vad, _) in enumerate(sessions):
+            tmp = os.path.join(str(tmp_path), 'f%d' % k)
+            os.makedirs(os.path.join(tmp, 'fea'))
+            synth.write_fea(os.path.join(tmp, 'fea', 'x.fea'), feats)
+            with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+                f.write(synth.vad_recipe_text('x.wav', vad))
+            _, final, _, _ = _run_scripts(tmp, e2, 'hip')
+            rows = re.findall(r'start-time=(\S+) end-time=(\S+) speaker=speaker_(\d+)', final)
+            want = [(float(a), float(b), int(c)) for a, b, c in rows]
+            assert got[k] == want, k
+    finally:
+        e2.close()
+
+
+def test_empty_and_short_turns(eng):
+    """Edge cases of dist_gw: a turn shorter than two windows gives only the tail
+    line; an empty turn list is a no-op."""
+    synth = pkg('synth')
+    feats, _, _ = synth.make_session(5, 30, 2)
+    eng.set_features(feats)
+    assert eng.gw([], 'BIC', 1.0, 0.0, 125.0, 375.0, 12.0, 125.0) == []
+    res = eng.gw([(100, 400), (0, 249), (10, 10)], 'BIC', 1.0, 0.0, 125.0, 375.0, 12.0, 125.0)
+    assert res[1].events == [] and res[1].final_start == 0.0
+    assert res[2].events == [] and res[2].final_start == 0.0
+    assert [e[0] for e in res[0].events].count('win') >= 1

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = load_cases()
 # reference modes not on the device yet (growing window with KL2)
-NOT_YET = {'A_cd_gw_kl2'}
+NOT_YET = set()
 
 
 @pytest.fixture(scope='module')
