@@ -16,6 +16,7 @@
 // the per-cluster log det terms are cached.
 #pragma once
 #include "spkd_device.hpp"
+#include "spkd_quad.hpp"
 #include "../../include/spkd.h"
 
 namespace spkd {
@@ -157,69 +158,174 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_pair_terms(
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
-        const double* __restrict__ stats, int64_t n_rec, int kind,
-        double* __restrict__ ld, double* __restrict__ aux, int* err) {
-    __shared__ double slabs[PT_WAVES][REC];
-    const int wave = threadIdx.x >> 6;
-    const int64_t c = (int64_t)blockIdx.x * PT_WAVES + wave;
+// Packed -> quad records (see spkd_quad.hpp).  The packed form (6 560 B) stays the
+// ABI format; the clustering kernels keep their working set as quad records.
+__global__ __launch_bounds__(256) void k_to_quadrec(const double* __restrict__ packed, int64_t n_rec,
+                                                    double* __restrict__ qr) {
+    const int64_t c = blockIdx.x;
     if (c >= n_rec) return;
-    double* slab = slabs[wave];
-    const double* R = stats + c * REC;
-    const double n = R[REC - 1];
-    double a[DA];
-    if (kind == SPKD_KL2) {
-        stage1(slab, R);
-        row_from_slab(slab, a);
-        const double mean_i = a[D] / n;
-        cov_rows(a, n);
-        kl2_aux_from_cov(a, mean_i, aux + c * AUX);
-        if (lane_id() == 0) ld[c] = 0.0;
-    } else {
-        auto form = [&](double (&q)[DA]) {
-            stage1(slab, R);
-            row_from_slab(slab, q);
-            cov_rows(q, n);
-        };
-        const double v = logdet_formed(a, err, form);
-        if (lane_id() == 0) ld[c] = v;
+    const double* g = packed + c * REC;
+    double* o = qr + c * QREC;
+    for (int e = threadIdx.x; e < QREC; e += 256) {
+        const int t = e & 15, sj = e >> 4;
+        const int s = sj / DA, j = sj - s * DA;
+        double v = 0.0;
+        if (t < QL) {
+            const int i = QL * s + t;
+            const int r = i < j ? i : j, cc = i < j ? j : i;
+            v = g[pk(r, cc)];
+        } else if (e == QREC_COUNT_AT) {
+            v = g[REC - 1];
+        }
+        o[e] = v;
     }
 }
 
-// ---------------------------------------------------------------------------
-// Distance between the cluster whose record is expanded in LDS (exA, count nA,
-// log det ldA) and the record C (count nC, log det ldC), staged through slab.
-// Returns the raw log det needed (union for BIC, weighted mean for GLR).
-__device__ __forceinline__ double pair_logdet(int kind, const double* exA, double nA,
-                                              const double* __restrict__ C, double nC,
-                                              double* slab, int* err) {
-    double a[DA];
-    const double n = nA + nC;
-    auto form = [&](double (&q)[DA]) {
-        stage1(slab, C);
-        row_from_expanded(exA, q);
-        if (kind == SPKD_BIC) {
-            row_acc_slab(slab, q, 1.0);
-            cov_rows(q, n);
-        } else {
-            const double al1 = (nA / n) / (nA - 1.0), al2 = (nC / n) / (nC - 1.0);
-            const double be1 = al1 / nA, be2 = al2 / nC;
-            const double s1i = q[D];
+// row-per-lane (single matrix) forms used by the pivoting fallback and by KL2
+__device__ __forceinline__ void single_rows_from_qr(const double* __restrict__ qr, double (&q)[DA]) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;           // lanes >= 39 mirror row 38 (ignored)
+    const int base = (i / QL) * DA * 16 + (i % QL);
 #pragma unroll
-            for (int j = 0; j < D; ++j) q[j] *= al1;
-            row_acc_slab(slab, q, al2);
-            int li = lane_id();
-            li = li > D ? D : li;
-            const double s2i = slab[pk_off(li) - li + D];
+    for (int j = 0; j < DA; ++j) q[j] = qr[base + j * 16];
+}
+
+// matrix whose log det a pair distance needs, row-per-lane layout
+__device__ __forceinline__ void single_pair_matrix(int kind, const double* __restrict__ qrA,
+                                                   const double* __restrict__ qrC, bool self,
+                                                   double (&q)[DA]) {
+    const double nA = qr_count(qrA);
+    single_rows_from_qr(qrA, q);
+    if (self) { cov_rows(q, nA); return; }
+    const double nC = qr_count(qrC), n = nA + nC;
+    double q2[DA];
+    single_rows_from_qr(qrC, q2);
+    if (kind == SPKD_BIC) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
-                double v = fma(-(be1 * s1i), s1j, q[j]);
-                q[j] = fma(-(be2 * s2i), s2j, v);
-            }
+        for (int j = 0; j < DA; ++j) q[j] += q2[j];
+        cov_rows(q, n);
+    } else {
+        const double al1 = (nA / n) / (nA - 1.0), al2 = (nC / n) / (nC - 1.0);
+        const double be1 = al1 / nA, be2 = al2 / nC;
+        const double s1i = q[D], s2i = q2[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
+            double v = fma(al2, q2[j], al1 * q[j]);
+            v = fma(-(be1 * s1i), s1j, v);
+            q[j] = fma(-(be2 * s2i), s2j, v);
         }
+    }
+}
+
+// Quad evaluation of the log det a distance needs for FOUR partner records at
+// once: the lane's DPP row handles partner qrC (or the cluster itself when self).
+// BIC: log det of the covariance of the union; GLR: of (nA S_A + nC S_C) / N.
+// ldsA: quad record of cluster A staged in LDS (all four matrices share it);
+// gA: the same record in global memory (fallback path only).
+__device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA, double nA,
+                                                   const double* __restrict__ gA,
+                                                   const double* __restrict__ qrC, bool self,
+                                                   const QuadLane& L, const double* const* qrC_by_m,
+                                                   const bool* self_by_m, int* err) {
+    QuadRows q;
+    double sv[QS], svc[QS];
+    const double nC = self ? 0.0 : qr_count(qrC);
+    const double n = nA + nC;
+    double wa = 1.0, wc = self ? 0.0 : 1.0;
+    if (kind == SPKD_GLR && !self) {
+        wa = (nA / n) / (nA - 1.0);
+        wc = (nC / n) / (nC - 1.0);
+    }
+    // phase 1: the partner's rows straight into the row registers (120 loads in
+    // flight, no extra registers); phase 2: slot by slot, q = wa * A + wc * C with
+    // A read from LDS.  The scheduling barriers keep the LDS reads of a slot from
+    // being hoisted above the previous slot (that would need 234 more VGPRs).
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q.r[s][j] = qrC[(s * DA + j) * 16 + L.t];
+        svc[s] = qrC[(s * DA + D) * 16 + L.t];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // A is the same for every partner of the caller's loop: an opaque lane offset keeps
+    // its 120 LDS reads inside the loop instead of pinned in 234 VGPRs across it
+    int ta = L.t;
+    asm volatile("" : "+v"(ta));
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q.r[s][j] = fma(wa, ldsA[(s * DA + j) * 16 + ta], wc * q.r[s][j]);
+        sv[s] = ldsA[(s * DA + D) * 16 + ta];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kind == SPKD_GLR && !self) {
+        double c1[QS], c2[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            c1[s] = -((wa / nA) * sv[s]);
+            c2[s] = -((wc / nC) * svc[s]);
+        }
+        QuadRank1<0>::run(q, c1, sv);
+        QuadRank1<0>::run(q, c2, svc);
+    } else {
+#pragma unroll
+        for (int s = 0; s < QS; ++s) sv[s] = fma(wc, svc[s], sv[s]);
+        quad_cov(q, sv, n);
+    }
+    auto form_single = [&](int mi, double (&a)[DA]) {
+        single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
     };
-    return logdet_formed(a, err, form);
+    return quad_logdet(q, L.m, err, form_single);
+}
+
+__device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
+    for (int e = tid; e < QREC; e += nthreads) lds[e] = g[e];
+}
+
+// ---------------------------------------------------------------------------
+// per-record cached terms: log det S (BIC / GLR) or the KL2 vectors
+__global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
+        const double* __restrict__ qr, int64_t n_rec, int kind,
+        double* __restrict__ ld, double* __restrict__ aux, int* err) {
+    const int wave = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * PT_WAVES + wave;
+    if (kind == SPKD_KL2) {
+        if (w >= n_rec) return;
+        const double* R = qr + w * QREC;
+        double a[DA];
+        single_rows_from_qr(R, a);
+        const double n = qr_count(R);
+        const double mean_i = a[D] / n;
+        cov_rows(a, n);
+        kl2_aux_from_cov(a, mean_i, aux + w * AUX);
+        if (lane_id() == 0) ld[w] = 0.0;
+        return;
+    }
+    if (w * 4 >= n_rec) return;
+    const QuadLane L = quad_lane();
+    const double* recs[4];
+    bool selfs[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        int64_t c = w * 4 + mi;
+        c = c < n_rec ? c : n_rec - 1;
+        recs[mi] = qr + c * QREC;
+        selfs[mi] = true;
+    }
+    int64_t c = w * 4 + L.m;
+    const bool valid = c < n_rec;
+    c = valid ? c : n_rec - 1;
+    const double* R = qr + c * QREC;
+    // every DPP row takes its own record as "A": formed in the single-matrix path
+    // of quad_pair_logdet with self = true through a per-lane pointer
+    QuadRows q;
+    double sv[QS];
+    quad_load_scaled(R, L.t, 1.0, q, sv);
+    quad_cov(q, sv, qr_count(R));
+    auto form_single = [&](int mi, double (&a)[DA]) { single_pair_matrix(kind, recs[mi], recs[mi], true, a); };
+    const double v = quad_logdet(q, L.m, err, form_single);
+    if (valid && L.t == 0) ld[c] = v;
 }
 
 __device__ __forceinline__ double finish_distance(int kind, double lambdac, double nA, double ldA,
@@ -242,65 +348,84 @@ __device__ __forceinline__ int find_problem(const int64_t* __restrict__ seg_off,
     return (int)lo;
 }
 
-constexpr int MX_WAVES = 8;
+constexpr int MX_WAVES = 4;
 
 // grid.x = total number of records; block g computes row a = g - seg_off[p] of
 // problem p: D[a][c] for c > a (and D[c][a] for variant 1), plus the diagonal /
-// lower-triangle initial values.
+// lower-triangle initial values.  Each wave evaluates four partners per pass.
 __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
-        const double* __restrict__ stats, const int64_t* __restrict__ seg_off, int64_t n_prob,
+        const double* __restrict__ ex, const int64_t* __restrict__ seg_off, int64_t n_prob,
         int variant, int kind, double lambdac,
         const double* __restrict__ ld, const double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
-    __shared__ double exA[DA * DA];
-    __shared__ double slabs[MX_WAVES][REC];
+    __shared__ double ldsA[QREC];
     const int64_t g = blockIdx.x;
     const int p = find_problem(seg_off, n_prob, g);
     const int64_t off = seg_off[p];
     const int64_t N = seg_off[p + 1] - off;
     const int64_t ra = g - off;
     double* Dm = mat + mat_off[p];
-    const double* A = stats + g * REC;
-    expand_to_lds(exA, A, threadIdx.x, MX_WAVES * WAVE);
-    // initial values of the cells this row owns and never computes
+    const double* A = ex + g * QREC;
+    stage_record(ldsA, A, threadIdx.x, MX_WAVES * WAVE);
     if (variant == 1) {
         if (threadIdx.x == 0) Dm[ra * N + ra] = MAXINT_F;
     } else {
         for (int64_t c = threadIdx.x; c <= ra; c += MX_WAVES * WAVE) Dm[ra * N + c] = __builtin_huge_val();
     }
     __syncthreads();
-    const double nA = A[REC - 1];
+    const double nA = ldsA[QREC_COUNT_AT];
     const double ldA = ld[g];
     const int wave = threadIdx.x >> 6;
+    const QuadLane L = quad_lane();
     double wmax = __builtin_nan(""), wmin = __builtin_nan("");
-    for (int64_t rc = ra + 1 + wave; rc < N; rc += MX_WAVES) {
-        const double* C = stats + (off + rc) * REC;
-        double d;
-        if (kind == SPKD_KL2) {
-            d = kl2_from_aux(aux + g * AUX, aux + (off + rc) * AUX);
-        } else {
-            const double nC = C[REC - 1];
-            const double ldx = pair_logdet(kind, exA, nA, C, nC, slabs[wave], err);
-            d = finish_distance(kind, lambdac, nA, ldA, nC, ld[off + rc], ldx);
+    if (kind == SPKD_KL2) {
+        for (int64_t rc = ra + 1 + wave; rc < N; rc += MX_WAVES) {
+            const double d = kl2_from_aux(aux + g * AUX, aux + (off + rc) * AUX);
+            if (lane_id() == 0) {
+                Dm[ra * N + rc] = d;
+                if (variant == 1) Dm[rc * N + ra] = d;
+            }
+            if (stat_valid(d)) {
+                wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                wmin = (wmin != wmin || d < wmin) ? d : wmin;
+            }
         }
-        if (lane_id() == 0) {
-            Dm[ra * N + rc] = d;
-            if (variant == 1) Dm[rc * N + ra] = d;
-        }
-        if (stat_valid(d)) {
-            wmax = (wmax != wmax || d > wmax) ? d : wmax;
-            wmin = (wmin != wmin || d < wmin) ? d : wmin;
+    } else {
+        for (int64_t base = ra + 1 + 4 * wave; base < N; base += 4 * MX_WAVES) {
+            const double* recs[4];
+            bool selfs[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                int64_t c = base + mi;
+                c = c < N ? c : N - 1;
+                recs[mi] = ex + (off + c) * QREC;
+                selfs[mi] = false;
+            }
+            int64_t rc = base + L.m;
+            const bool valid = rc < N;
+            rc = valid ? rc : N - 1;
+            const double* C = ex + (off + rc) * QREC;
+            const double ldx = quad_pair_logdet(kind, ldsA, nA, A, C, false, L, recs, selfs, err);
+            const double d = finish_distance(kind, lambdac, nA, ldA, qr_count(C), ld[off + rc], ldx);
+            if (valid && L.t == 0) {
+                Dm[ra * N + rc] = d;
+                if (variant == 1) Dm[rc * N + ra] = d;
+            }
+            if (valid && stat_valid(d)) {
+                wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                wmin = (wmin != wmin || d < wmin) ? d : wmin;
+            }
         }
     }
-    if (variant == 1 && lane_id() == 0) {
+    if (variant == 1 && (kind == SPKD_KL2 ? lane_id() == 0 : L.t == 0)) {
         if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
         if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
     }
 }
 
 // ---------------------------------------------------------------------------
-constexpr int AHC_WAVES = 16;
+constexpr int AHC_WAVES = 4;
 constexpr int AHC_TPB = AHC_WAVES * WAVE;
 
 struct ArgMin {
@@ -314,10 +439,10 @@ __device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
     if (y.nan_idx < x.nan_idx) x.nan_idx = y.nan_idx;
 }
 
-// One workgroup per problem.  stats is a private working copy (records are
-// summed in place as clusters merge).
+// One workgroup per problem.  ex is a private working copy of the expanded
+// records (summed in place as clusters merge).  Dynamic LDS: int32 ids[N + 1].
 __global__ __launch_bounds__(AHC_TPB) void k_ahc(
-        double* __restrict__ stats, const int64_t* __restrict__ seg_off,
+        double* __restrict__ ex, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double lambdac, double threshold,
         double* __restrict__ ld, double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
@@ -325,14 +450,15 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         int32_t* __restrict__ out_n, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
         double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
         double* __restrict__ final_max, double* __restrict__ final_min, int* err) {
-    extern __shared__ double lds[];
-    double* exA = lds;                                  // DA*DA
-    double* slabs = lds + DA * DA;                      // AHC_WAVES * REC
-    ArgMin* red = (ArgMin*)(slabs + AHC_WAVES * REC);   // AHC_WAVES entries
+    extern __shared__ int32_t ids[];                    // alive partner slots of the merged cluster
+    __shared__ double ldsA[QREC];
+    __shared__ ArgMin red[AHC_WAVES];
     __shared__ ArgMin best;
     __shared__ int s_cnt[2];
+    __shared__ int s_nids;
     __shared__ double s_tmax[AHC_WAVES + 1];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const QuadLane L = quad_lane();
     const int p = blockIdx.x;
     const int64_t off = seg_off[p];
     const long long N = seg_off[p + 1] - off;
@@ -347,19 +473,23 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     const long long INF_IDX = 0x7fffffffffffffffLL;
     double fmax = 0.0, fmin = 0.0;
     while (true) {
-        // ---- 1. min / argmin over the alive sub-matrix, numpy semantics:
-        // first occurrence in row-major order; any NaN -> min is NaN and argmin is
-        // the first NaN.  (distances.min(), distances.argmin(): CL1:203-204)
+        // ---- 1. min / argmin over the alive sub-matrix, numpy semantics: first
+        // occurrence in row-major order; any NaN -> min is NaN and argmin the first
+        // NaN (distances.min(), distances.argmin(): CL1:203-204).  Wave per row.
         ArgMin mine;
         mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
         double tmax = -__builtin_huge_val();
-        for (long long l = tid; l < N * N; l += AHC_TPB) {
-            const long long r = l / N, c = l - r * N;
-            if (!al[r] || !al[c]) continue;
-            const double v = Dm[l];
-            if (v != v) { if (l < mine.nan_idx) mine.nan_idx = l; continue; }
-            if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
-            tmax = v > tmax ? v : tmax;
+        for (long long r = wave; r < N; r += AHC_WAVES) {
+            if (!al[r]) continue;
+            const double* row = Dm + r * N;
+            for (long long c = lane; c < N; c += WAVE) {
+                if (!al[c]) continue;
+                const double v = row[c];
+                const long long l = r * N + c;
+                if (v != v) { if (l < mine.nan_idx) mine.nan_idx = l; continue; }
+                if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+                tmax = v > tmax ? v : tmax;
+            }
         }
 #pragma unroll
         for (int s = 1; s < WAVE; s <<= 1) {
@@ -387,13 +517,14 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
         if (!go) break;
         const long long r0 = index / N, c0 = index - r0 * N;
-        if (r0 == c0) {                       // a diagonal cell won: see DESIGN.md (degenerate)
+        if (r0 == c0) {                       // a diagonal cell won: degenerate
             if (tid == 0) atomicOr(err, ERR_DEGENERATE_MERGE);
             break;
         }
         const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
         // compacted indices = number of alive slots in front
         if (tid < 2) s_cnt[tid] = 0;
+        if (tid == 0) s_nids = 1;
         __syncthreads();
         {
             int ca = 0, cb = 0;
@@ -408,45 +539,58 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             const int64_t o = off + n_merges;
             out_a[o] = s_cnt[0]; out_b[o] = s_cnt[1]; out_d[o] = mind;
             al[sb] = 0;
+            ids[0] = (int32_t)sa;             // job 0 = the merged cluster itself
         }
         n_merges++;
         m--;
         // ---- 2. merge the statistics (speakers[a].extend(speakers[b]))
-        double* A = stats + (off + sa) * REC;
-        const double* B = stats + (off + sb) * REC;
-        for (int e = tid; e < REC; e += AHC_TPB) A[e] += B[e];
+        double* A = ex + (off + sa) * QREC;
+        const double* B = ex + (off + sb) * QREC;
+        for (int e = tid; e < QREC; e += AHC_TPB) {
+            const double v = A[e] + B[e];
+            A[e] = v;
+            ldsA[e] = v;
+        }
         __syncthreads();
-        expand_to_lds(exA, A, tid, AHC_TPB);
+        // partner list (order is irrelevant: results are scattered by slot)
+        for (long long c = tid; c < N; c += AHC_TPB) {
+            if (c != sa && al[c]) ids[atomicAdd(&s_nids, 1)] = (int32_t)c;
+        }
         __syncthreads();
-        const double nA = exA[D * DA + D];
-        // ---- 3. phase A: wave 0 refreshes the merged cluster's own terms while
-        // the other waves start on the log dets of the unions.
+        const int nids = s_nids;
+        const double nA = ldsA[QREC_COUNT_AT];
+        // ---- 3. the merged cluster's own term and the log dets of its unions
         if (kind == SPKD_KL2) {
             if (wave == 0) {
                 double a[DA];
-                row_from_expanded(exA, a);
+                single_rows_from_qr(A, a);
                 const double mean_i = a[D] / nA;
                 cov_rows(a, nA);
                 kl2_aux_from_cov(a, mean_i, aux + (off + sa) * AUX);
             }
         } else {
-            // job -1 = self, jobs 0.. = alive slots other than sa
-            for (long long c = (long long)wave - 1; c < N; c += AHC_WAVES) {
-                if (c < 0) {
-                    double a[DA];
-                    auto form = [&](double (&q)[DA]) { row_from_expanded(exA, q); cov_rows(q, nA); };
-                    const double v = logdet_formed(a, err, form);
-                    if (lane == 0) ldp[sa] = v;
-                    continue;
+            for (int base = 4 * wave; base < nids; base += 4 * AHC_WAVES) {
+                const double* recs[4];
+                bool selfs[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    int k = base + mi;
+                    k = k < nids ? k : nids - 1;
+                    recs[mi] = ex + (off + ids[k]) * QREC;
+                    selfs[mi] = (k == 0);
                 }
-                if (c == sa || !al[c]) continue;
-                const double* C = stats + (off + c) * REC;
-                const double ldx = pair_logdet(kind, exA, nA, C, C[REC - 1], slabs + wave * REC, err);
-                if (lane == 0) tp[c] = ldx;
+                int k = base + L.m;
+                const bool valid = k < nids;
+                k = valid ? k : nids - 1;
+                const int32_t slot = ids[k];
+                const double v = quad_pair_logdet(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
+                if (valid && L.t == 0) {
+                    if (k == 0) ldp[sa] = v; else tp[slot] = v;
+                }
             }
         }
         __syncthreads();
-        // ---- 4. phase B: finish the distances, update row (and column) sa
+        // ---- 4. finish the distances, update row (and column) sa
         double wmax = __builtin_nan(""), wmin = __builtin_nan("");
         if (kind == SPKD_KL2) {
             for (long long c = wave; c < N; c += AHC_WAVES) {
@@ -465,7 +609,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             const double ldA = ldp[sa];
             for (long long c = tid; c < N; c += AHC_TPB) {
                 if (c == sa || !al[c]) continue;
-                const double nC = stats[(off + c) * REC + REC - 1];
+                const double nC = qr_count(ex + (off + c) * QREC);
                 const double d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
                 Dm[sa * N + c] = d;
                 if (variant == 1) Dm[c * N + sa] = d;

@@ -151,8 +151,6 @@ spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
             return SPKD_EHIP;
         }
     // kernels that need more than 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)k_ahc, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)((DA * DA + AHC_WAVES * REC) * sizeof(double) + AHC_WAVES * sizeof(ArgMin)));
     (void)hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)(GW_LDS_DOUBLES * sizeof(double)));
     *out = c;
@@ -290,6 +288,7 @@ spkd_status spkd_pair_terms(spkd_ctx* c, const double* d_stats, const int32_t* h
 // ------------------------------------------------------------------ clustering internals
 namespace {
 struct AhcBuffers {
+    double* ex;
     double* ld;
     double* aux;
     double* mat;
@@ -330,14 +329,19 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     B.smin = B.smax + n_prob;
     HIPCHK(c, hipMemsetAsync(B.smax, 0x00, (size_t)n_prob * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(B.smin, 0xff, (size_t)n_prob * sizeof(unsigned long long), c->stream));
+    if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * QREC * sizeof(double), &p)) != SPKD_OK) return st;
+    B.ex = (double*)p;
     if (n_total > 0) {
-        const unsigned blocks = (unsigned)((n_total + PT_WAVES - 1) / PT_WAVES);
+        // KL2: one wave per record; BIC / GLR: four records per wave
+        const int64_t per_block = kind == SPKD_KL2 ? PT_WAVES : 4 * PT_WAVES;
+        const unsigned blocks = (unsigned)((n_total + per_block - 1) / per_block);
+        hipLaunchKernelGGL(k_to_quadrec, dim3((unsigned)n_total), dim3(256), 0, c->stream, d_stats, n_total, B.ex);
         TIMED(c, SPKD_T_CLUSTER_PREP,
               hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
-                                 d_stats, n_total, kind, B.ld, B.aux, c->d_err));
+                                 (const double*)B.ex, n_total, kind, B.ld, B.aux, c->d_err));
         TIMED(c, SPKD_T_MATRIX,
               hipLaunchKernelGGL(k_matrix, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
-                                 d_stats, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
+                                 (const double*)B.ex, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
                                  (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
                                  B.smax, B.smin, c->d_err));
     }
@@ -387,14 +391,11 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     if (st != SPKD_OK) return st;
     AhcBuffers B;
     int64_t n_total = 0;
-    // private working copy of the records (merged in place)
-    void* wp = nullptr;
-    const int64_t nt = h_seg_off[n_prob];
-    if ((st = scratch(c, S_AHC_STATS, (size_t)nt * REC * sizeof(double), &wp)) != SPKD_OK) return st;
-    double* work = (double*)wp;
-    HIPCHK(c, hipMemcpyAsync(work, d_stats, (size_t)nt * REC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    // ahc_prepare expands the records into a private working copy (merged in place)
     std::vector<int64_t> offs;
-    if ((st = ahc_prepare(c, work, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs)) != SPKD_OK) return st;
+    if ((st = ahc_prepare(c, d_stats, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs)) != SPKD_OK) return st;
+    int64_t n_max = 0;
+    for (int64_t p = 0; p < n_prob; ++p) n_max = std::max<int64_t>(n_max, h_seg_off[p + 1] - h_seg_off[p]);
     // outputs + per-slot scratch
     void* op = nullptr;
     const size_t out_bytes = (size_t)n_total * (2 * sizeof(int32_t) + 2 * sizeof(double) + sizeof(int32_t)) +
@@ -408,10 +409,13 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     int32_t* d_b = d_a + n_total;
     int32_t* d_alive = d_b + n_total;
     int32_t* d_n = d_alive + n_total;
-    const size_t lds = (DA * DA + AHC_WAVES * REC) * sizeof(double) + AHC_WAVES * sizeof(ArgMin);
+    const size_t lds = (size_t)(n_max + 4) * sizeof(int32_t);
+    if (lds > 150 * 1024) return fail(c, SPKD_EINVAL, "clustering problem too large for one workgroup's LDS");
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_ahc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TIMED(c, SPKD_T_AHC,
           hipLaunchKernelGGL(k_ahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
-                             work, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
+                             B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                              P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
                              d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
     HIPCHK(c, hipGetLastError());

@@ -1,0 +1,195 @@
+// Quad elimination: FOUR 39x39 matrices per wave64, one per 16-lane DPP row.
+//
+// Inside a DPP row, lanes t = 0..12 each hold three rows of their matrix
+// (row 13*s + t in slot s = 0, 1, 2; 39 doubles per slot); lanes 13..15 idle.
+// The pivot row of step k lives in lane (k % 13) slot (k / 13) of every DPP row, so
+// one `v_mov_b64_dpp ... row_newbcast` broadcasts the pivot-row element of all four
+// matrices at once -- no v_readlane, no SGPR round trip, no LDS.  Slots whose rows
+// are all above the pivot are skipped (triangular saving): 1 820 fp64 FMAs + 741
+// DPP moves per FOUR determinants, against 741 FMAs + 1 482 v_readlane (+ hazard
+// nops) per ONE in the row-per-lane form of spkd_device.hpp.
+#pragma once
+#include "spkd_device.hpp"
+
+namespace spkd {
+
+constexpr int QL = 13;        // row-carrying lanes per DPP row
+constexpr int QS = 3;         // row slots per lane
+
+struct QuadRows {
+    double r[QS][D];
+};
+
+// broadcast lane K (0..15) of every 16-lane row to the whole row
+template <int K>
+__device__ __forceinline__ double bcast16(double v) {
+    const long long x = __double_as_longlong(v);
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, x, 0x150 + K, 0xf, 0xf, true));
+}
+
+template <int K>
+struct QuadStep {
+    static __device__ __forceinline__ void run(QuadRows& q, double& det, bool& ok) {
+        constexpr int S = K / QL, T = K % QL;
+        const double piv = bcast16<T>(q.r[S][K]);
+        ok = ok && (piv > 0.0) && (piv < __builtin_huge_val());
+        det *= piv;
+        const double inv = 1.0 / piv;
+        double l[QS];
+#pragma unroll
+        for (int s = S; s < QS; ++s) l[s] = -(q.r[s][K] * inv);
+#pragma unroll
+        for (int j = K + 1; j < D; ++j) {
+            const double u = bcast16<T>(q.r[S][j]);
+#pragma unroll
+            for (int s = S; s < QS; ++s) q.r[s][j] = fma(l[s], u, q.r[s][j]);
+        }
+        QuadStep<K + 1>::run(q, det, ok);
+    }
+};
+
+template <>
+struct QuadStep<D> {
+    static __device__ __forceinline__ void run(QuadRows&, double&, bool&) {}
+};
+
+// det (per DPP row, i.e. per matrix) of four symmetric positive definite matrices.
+// Returns, per lane, whether its matrix met only positive finite pivots.
+__device__ __forceinline__ bool quad_det_nopivot(QuadRows& q, double& det_out) {
+    double det = 1.0;
+    bool ok = true;
+    QuadStep<0>::run(q, det, ok);
+    det_out = det;
+    return ok;
+}
+
+}  // namespace spkd
+
+// ===========================================================================
+// Quad records: the storage format the clustering kernels keep their working set
+// in.  QREC = 3 slots x 40 columns x 16 lanes doubles (15 360 B):
+//     qr[(s * 40 + j) * 16 + t] = M(13 s + t, j)   for t < 13 (M = augmented moments)
+// so that a wave's load of (slot s, column j) is one fully used 128-B line per
+// DPP row -- perfectly coalesced for the quad row layout.  Column 39 holds the
+// sums; the frame count sits in the padding lane 15 of (slot 0, column 39).
+// Records add component-wise (padding stays zero).
+// ===========================================================================
+namespace spkd {
+
+constexpr int QREC = QS * DA * 16;
+constexpr int QREC_COUNT_AT = (0 * DA + D) * 16 + 15;
+
+__host__ __device__ constexpr int qr_index(int i, int j) { return ((i / QL) * DA + j) * 16 + (i % QL); }
+
+struct QuadLane {
+    int m;       // matrix index inside the wave (DPP row), 0..3
+    int t;       // lane inside the DPP row, 0..15
+};
+
+__device__ __forceinline__ QuadLane quad_lane() {
+    QuadLane L;
+    const int lane = lane_id();
+    L.m = lane >> 4;
+    L.t = lane & 15;
+    return L;
+}
+
+__device__ __forceinline__ double qr_count(const double* __restrict__ qr) { return qr[QREC_COUNT_AT]; }
+
+// q = w * record rows (global or LDS pointer); sv[s] = sums column
+__device__ __forceinline__ void quad_load_scaled(const double* __restrict__ qr, int t, double w,
+                                                 QuadRows& q, double (&sv)[QS]) {
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q.r[s][j] = w * qr[(s * DA + j) * 16 + t];
+        sv[s] = qr[(s * DA + D) * 16 + t];
+    }
+}
+
+// q += w * record rows; sv2[s] = that record's sums column
+__device__ __forceinline__ void quad_fma_record(const double* __restrict__ qr, int t, double w,
+                                                QuadRows& q, double (&sv2)[QS]) {
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q.r[s][j] = fma(w, qr[(s * DA + j) * 16 + t], q.r[s][j]);
+        sv2[s] = qr[(s * DA + D) * 16 + t];
+    }
+}
+
+// rank-one update q[s][j] += c[s] * bcast(v)[j] for all j, where v[s] holds the
+// per-row values of a vector (same distribution as the rows)
+template <int J>
+struct QuadRank1 {
+    static __device__ __forceinline__ void run(QuadRows& q, const double (&c)[QS], const double (&v)[QS]) {
+        constexpr int S = J / QL, T = J % QL;
+        const double vj = bcast16<T>(v[S]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) q.r[s][J] = fma(c[s], vj, q.r[s][J]);
+        QuadRank1<J + 1>::run(q, c, v);
+    }
+};
+template <>
+struct QuadRank1<D> {
+    static __device__ __forceinline__ void run(QuadRows&, const double (&)[QS], const double (&)[QS]) {}
+};
+
+// np.cov semantics on raw moments, in place: S_ij = (Q_ij - s_i s_j / n) / (n - 1)
+__device__ __forceinline__ void quad_cov(QuadRows& q, const double (&sv)[QS], double n) {
+    const double inv_n = 1.0 / n, f = 1.0 / (n - 1.0);
+    double c[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) c[s] = -(sv[s] * inv_n);
+    QuadRank1<0>::run(q, c, sv);
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+        for (int j = 0; j < D; ++j) q.r[s][j] *= f;
+}
+
+// per-lane flag: every entry of the lane's matrix is finite (DPP-row wide AND)
+__device__ __forceinline__ bool quad_finite(const QuadRows& q, int m) {
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+        for (int j = 0; j < D; ++j) ok = ok && (fabs(q.r[s][j]) < __builtin_huge_val());
+    const unsigned long long bad = __ballot(!ok);
+    return ((bad >> (16 * m)) & 0xffffull) == 0ull;
+}
+
+// log(det) of the four matrices held in q (per lane: its own matrix).  Matrices
+// that meet a non-positive pivot are redone one at a time in the row-per-lane
+// layout with partial pivoting: form_single(mi, a) must fill matrix mi there.
+// Non-finite matrices raise ERR_NONFINITE and give NaN.
+template <class FormSingle>
+__device__ __forceinline__ double quad_logdet(QuadRows& q, int m, int* err, FormSingle form_single) {
+    const bool fin = quad_finite(q, m);
+    double det;
+    bool ok = quad_det_nopivot(q, det);
+    ok = ok && fin;
+    double ld = log(det);
+    const unsigned long long badmask = __ballot(!ok);
+#ifndef SPKD_NO_FALLBACK
+    if (badmask) {
+#pragma unroll 1
+        for (int mi = 0; mi < 4; ++mi) {
+            if (((badmask >> (16 * mi)) & 0xffffull) == 0ull) continue;   // wave-uniform
+            double a[DA];
+            form_single(mi, a);
+            double v;
+            if (!rows_finite(a)) {
+                if (lane_id() == 0) atomicOr(err, ERR_NONFINITE);
+                v = __builtin_nan("");
+            } else {
+                v = log(det_pivoted(a));
+            }
+            if (m == mi) ld = v;
+        }
+    }
+#endif
+    return ld;
+}
+
+}  // namespace spkd
