@@ -2,24 +2,27 @@
 // and sliding window (dist_sw, spk-change-detection.py:291-357, distances only).
 //
 // One workgroup per VAD turn.  Phase 1 turns the turn's frames into prefix
-// statistics snapshots every SNAP_G frames (each frame is read once, coalesced,
-// staged through LDS, fp64 accumulation in frame order).  Phase 2 evaluates
-// candidate split points: the statistics of any frame range [x, y) are
-// R(y) - R(x) with R(t) = snapshot[t / G] + the <= G-1 edge frames, so a
-// candidate costs one record read and one or two 39x39 factorisations instead of
-// two np.cov passes over raw frames.  The growing-window decision chain (a float
-// state machine with int() truncation) runs on the device with
-// the exact operation order of the reference.
+// statistics snapshots every SNAP_G frames, stored as quad records (each frame is
+// read once, coalesced, staged through LDS, fp64 accumulation in frame order).
+// Phase 2 evaluates candidate split points: the statistics of any frame range
+// [x, y) are R(y) - R(x) with R(t) = snapshot[t / G] + the <= G-1 edge frames, so a
+// candidate costs one record read and one or two 39x39 eliminations instead of two
+// np.cov passes over raw frames.  Four candidates share a wave (quad layout,
+// spkd_quad.hpp).  The growing-window decision chain (a float state machine with
+// int() truncation) runs on the device with the exact operation
+// order of the reference.
 #pragma once
 #include "spkd_device.hpp"
+#include "spkd_quad.hpp"
 #include "spkd_cluster.hpp"
 #include "../../include/spkd.h"
 
 namespace spkd {
 
-constexpr int SNAP_G = 8;
+constexpr int SNAP_G = 16;
 constexpr int CD_TILE = 64;
 constexpr double NEG_MAXINT_M1 = -9223372036854775808.0;   // -sys.maxint - 1
+constexpr int QUSE = QS * DA * QL;                         // row-carrying entries of a quad record
 
 struct TurnDesc {
     int64_t begin;       // first frame of the turn in the frame array
@@ -31,22 +34,32 @@ struct TurnDesc {
     int64_t ev_cap;      // event slots owned by this turn
 };
 
-// Phase 1: snapshots snap[j] = sum over turn frames [0, G*j), j = 0 .. len / G.
+// e in [0, QUSE) -> quad-record index and the (row, column) it holds
+__device__ __forceinline__ void quse_decode(int e, int& idx, int& i, int& j) {
+    const int s = e / (DA * QL), rem = e - s * (DA * QL);
+    j = rem / QL;
+    const int t = rem - j * QL;
+    i = QL * s + t;
+    idx = (s * DA + j) * 16 + t;
+}
+
+// Phase 1: snapshots snap[k] = moments of turn frames [0, G*k), k = 0 .. len / G.
 template <int TPB>
 __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long long n,
                                              double* __restrict__ snap, float* xs) {
-    constexpr int EPT = (REC + TPB - 1) / TPB;
+    constexpr int EPT = (QUSE + TPB - 1) / TPB;
     const int tid = threadIdx.x;
-    int er[EPT], ec[EPT];
+    int eidx[EPT], er[EPT], ec[EPT];
     double acc[EPT];
 #pragma unroll
     for (int m = 0; m < EPT; ++m) {
         int e = tid + TPB * m;
-        if (e >= REC) e = REC - 1;
-        decode_entry(e, er[m], ec[m]);
+        if (e >= QUSE) e = QUSE - 1;
+        quse_decode(e, eidx[m], er[m], ec[m]);
         acc[m] = 0.0;
-        if (tid + TPB * m < REC) snap[tid + TPB * m] = 0.0;
+        if (tid + TPB * m < QUSE) snap[eidx[m]] = 0.0;
     }
+    if (tid == 0) snap[QREC_COUNT_AT] = 0.0;
     for (long long t0 = 0; t0 < n; t0 += CD_TILE) {
         const int tl = (int)((n - t0) < CD_TILE ? (n - t0) : CD_TILE);
         const float* src = fr + t0 * D;
@@ -62,52 +75,117 @@ __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long 
                 acc[m] = fma((double)xs[f * DA + er[m]], (double)xs[f * DA + ec[m]], acc[m]);
             const long long t = t0 + f + 1;
             if ((t % SNAP_G) == 0) {
-                double* dst = snap + (t / SNAP_G) * REC;
+                double* dst = snap + (t / SNAP_G) * QREC;
 #pragma unroll
                 for (int m = 0; m < EPT; ++m)
-                    if (tid + TPB * m < REC) dst[tid + TPB * m] = acc[m];
+                    if (tid + TPB * m < QUSE) dst[eidx[m]] = acc[m];
+                if (tid == 0) dst[QREC_COUNT_AT] = (double)t;
             }
         }
         __syncthreads();
     }
 }
 
-// Row-layout prefix statistics R(t): snapshot + edge frames, in frame order.
-__device__ __forceinline__ void prefix_rows(double (&q)[DA], double* slab,
-                                            const double* __restrict__ snap,
-                                            const float* __restrict__ fr, long long t) {
-    const long long j = t / SNAP_G;
-    stage1(slab, snap + j * REC);
-    row_from_slab(slab, q);
+// LDS quad record of R(t), built by the whole workgroup (padding lanes untouched:
+// the caller zeroes them once).  The <= G-1 edge frames are staged in LDS first
+// (one coalesced read), then every entry adds its products in frame order.
+// Contains block-wide barriers: call from uniform control flow.
+__device__ __forceinline__ void build_record_lds(double* lds, const double* __restrict__ snap,
+                                                 const float* __restrict__ fr, long long t,
+                                                 float* xs, int tid, int nthreads) {
+    const long long k = t / SNAP_G;
+    const int ne = (int)(t - k * SNAP_G);
+    const float* src = fr + k * SNAP_G * D;
+    for (int idx = tid; idx < ne * D; idx += nthreads) {
+        const int f = idx / D, c = idx - f * D;
+        xs[f * DA + c] = src[idx];
+    }
+    if (tid < ne) xs[tid * DA + D] = 1.0f;
+    __syncthreads();
+    const double* s = snap + k * QREC;
+    for (int e = tid; e < QUSE; e += nthreads) {
+        int idx, i, j;
+        quse_decode(e, idx, i, j);
+        double v = s[idx];
+        for (int f = 0; f < ne; ++f) v = fma((double)xs[f * DA + i], (double)xs[f * DA + j], v);
+        lds[idx] = v;
+    }
+    __syncthreads();
+}
+
+// Quad-layout prefix statistics: DPP row m gets R(tpos) for its own tpos.
+// q = rows (columns 0..38), sv = sums column.  The <= G-1 edge frames of the four
+// positions are first copied to a per-wave LDS buffer (coalesced, few registers),
+// the snapshot rows are loaded straight into the row registers, then the edge
+// frames are added in frame order (positions with fewer edge frames add zeros).
+constexpr int EDGE_FLOATS = (SNAP_G - 1) * D;          // per position
+constexpr int EDGE_WAVE_FLOATS = 4 * EDGE_FLOATS;      // per wave
+
+__device__ __forceinline__ void quad_prefix_rows(QuadRows& q, double (&sv)[QS],
+                                                 const double* __restrict__ snap,
+                                                 const float* __restrict__ fr, long long tpos,
+                                                 const QuadLane& L, float* edge /* per-wave LDS */) {
+    const long long k = tpos / SNAP_G;
+    const double* s = snap + k * QREC;
+    const int ne = (int)(tpos - k * SNAP_G);
     const int lane = lane_id();
-    for (long long f = j * SNAP_G; f < t; ++f) {
-        const float x = (lane < D) ? fr[f * D + lane] : 1.0f;
-        const double xi = (double)x;
+    // stage the edge frames of the four positions (contiguous floats each)
 #pragma unroll
-        for (int c = 0; c < DA; ++c) {
-            const double xc = readlane_d(xi, c);
-            q[c] = fma(xi, xc, q[c]);
+    for (int mi = 0; mi < 4; ++mi) {
+        const long long km = __shfl(k, 16 * mi);
+        const int nem = __shfl(ne, 16 * mi);
+        const float* src = fr + km * SNAP_G * D;
+        for (int idx = lane; idx < nem * D; idx += WAVE) edge[mi * EDGE_FLOATS + idx] = src[idx];
+    }
+#pragma unroll
+    for (int ss = 0; ss < QS; ++ss) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q.r[ss][j] = s[(ss * DA + j) * 16 + L.t];
+        sv[ss] = s[(ss * DA + D) * 16 + L.t];
+    }
+    int mx = ne;
+    mx = max(mx, __shfl_xor(mx, 16));
+    mx = max(mx, __shfl_xor(mx, 32));
+    mx = uniform_i(mx);
+    const float* mine = edge + L.m * EDGE_FLOATS;
+    const bool carrier = L.t < QL;
+#pragma unroll 1
+    for (int e = 0; e < mx; ++e) {
+        double x[QS];
+#pragma unroll
+        for (int ss = 0; ss < QS; ++ss) {
+            const float xf = (carrier && e < ne) ? mine[e * D + QL * ss + (carrier ? L.t : 0)] : 0.0f;
+            x[ss] = (double)xf;
+            sv[ss] += x[ss];
         }
+        QuadRank1<0>::run(q, x, x);
     }
 }
 
-// Expanded LDS image of R(t), built by the whole workgroup.
-__device__ __forceinline__ void build_expanded(double* ex, const double* __restrict__ snap,
-                                               const float* __restrict__ fr, long long t,
-                                               int tid, int nthreads) {
-    const long long j = t / SNAP_G;
-    const double* s = snap + j * REC;
-    for (int idx = tid; idx < DA * DA; idx += nthreads) {
-        const int c = idx / DA, i = idx - c * DA;
-        const int r0 = i < c ? i : c, c0 = i < c ? c : i;
-        double v = s[pk(r0, c0)];
-        for (long long f = j * SNAP_G; f < t; ++f) {
-            const float xi = (i < D) ? fr[f * D + i] : 1.0f;
-            const float xc = (c < D) ? fr[f * D + c] : 1.0f;
-            v = fma((double)xi, (double)xc, v);
+// Row-per-lane (single matrix) prefix rows, used by KL2 and by the pivoting fallback.
+__device__ __forceinline__ void single_prefix_rows(double (&q)[DA], const double* __restrict__ snap,
+                                                   const float* __restrict__ fr, long long t) {
+    const long long k = t / SNAP_G;
+    single_rows_from_qr(snap + k * QREC, q);
+    const int lane = lane_id();
+    for (long long f = k * SNAP_G; f < t; ++f) {
+        const float x = (lane < D) ? fr[f * D + lane] : 0.0f;
+        const double xi = (double)x;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double xc = readlane_d(xi, c);
+            q[c] = fma(xi, xc, q[c]);
         }
-        ex[idx] = v;
+        q[D] += xi;
     }
+}
+
+__device__ __forceinline__ void single_rows_from_lds(const double* lds, double (&q)[DA]) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;
+    const int base = (i / QL) * DA * 16 + (i % QL);
+#pragma unroll
+    for (int j = 0; j < DA; ++j) q[j] = lds[base + j * 16];
 }
 
 struct BestD {
@@ -158,18 +236,126 @@ __device__ __forceinline__ void log_cand(spkd_cand_log* log, long long cap, unsi
     }
 }
 
-constexpr int GW_WAVES = 8;
-constexpr int GW_TPB = GW_WAVES * WAVE;
-constexpr int GW_LDS_DOUBLES = 2 * DA * DA + GW_WAVES * REC;
+// which matrix of a split [a, b) | [b, c) a pass forms
+enum { PASS_RIGHT = 0, PASS_LEFT = 1, PASS_GLR = 2, PASS_POOLED = 3 };
 
-// Candidate scratch per slot k: cand[0*cap + k] = i value, [1*cap + k] = memoised
-// left term (BIC: 0.5 N1 log det S1; GLR: log det S1), [2*cap + k] = right log det
-// or finished distance.
+// single-matrix form of a pass (fallback / KL2): rows of the moment difference,
+// then covariance (or GLR's weighted covariance)
+__device__ __forceinline__ void single_split_matrix(int pass, const double* ldsRa, const double* ldsRc,
+                                                    const double* __restrict__ snap,
+                                                    const float* __restrict__ fr, long long a,
+                                                    long long b, long long c, double (&q)[DA]) {
+    double ra[DA], rc[DA];
+    if (pass == PASS_POOLED) {
+        single_rows_from_lds(ldsRc, q);
+        single_rows_from_lds(ldsRa, ra);
+#pragma unroll
+        for (int j = 0; j < DA; ++j) q[j] -= ra[j];
+        cov_rows(q, (double)(c - a));
+        return;
+    }
+    single_prefix_rows(q, snap, fr, b);
+    const double n1 = (double)(b - a), n2 = (double)(c - b), n = n1 + n2;
+    if (pass == PASS_RIGHT) {
+        single_rows_from_lds(ldsRc, rc);
+#pragma unroll
+        for (int j = 0; j < DA; ++j) q[j] = rc[j] - q[j];
+        cov_rows(q, n2);
+    } else if (pass == PASS_LEFT) {
+        single_rows_from_lds(ldsRa, ra);
+#pragma unroll
+        for (int j = 0; j < DA; ++j) q[j] -= ra[j];
+        cov_rows(q, n1);
+    } else {
+        single_rows_from_lds(ldsRa, ra);
+        single_rows_from_lds(ldsRc, rc);
+        const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
+        const double be1 = al1 / n1, be2 = al2 / n2;
+        const double s1i = q[D] - ra[D], s2i = rc[D] - q[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double q1 = q[j] - ra[j], q2 = rc[j] - q[j];
+            const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
+            double v = fma(al2, q2, al1 * q1);
+            v = fma(-(be1 * s1i), s1j, v);
+            q[j] = fma(-(be2 * s2i), s2j, v);
+        }
+    }
+}
+
+// log det of one pass for the four split points held by the wave (DPP row m: split b).
+// Every pass is the same straight-line code with per-pass coefficients (a switch
+// over differently shaped paths makes the compiler hoist the LDS reads common to
+// several branches above the switch and spill hundreds of registers):
+//     q  = al * R(b) + be * R(a) + ga * R(c)           (moments, rows + sums column)
+//     q += c1 v1^T + c2 v2^T   (al, be, ga, c1 carry the covariance scale f)
+//   right  [b, c): al = -1, be =  0, ga = 1; c1 = -s / n2, v1 = s;  f = 1 / (n2 - 1)
+//   left   [a, b): al =  1, be = -1, ga = 0; c1 = -s / n1, v1 = s;  f = 1 / (n1 - 1)
+//   pooled [a, c): al =  0, be = -1, ga = 1; c1 = -s / N,  v1 = s;  f = 1 / (N - 1)
+//   GLR: al1 (Rb - Ra) + al2 (Rc - Rb) - be1 s1 s1^T - be2 s2 s2^T;  f = 1
+__device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsRa, const double* ldsRc,
+                                                    const double* __restrict__ snap,
+                                                    const float* __restrict__ fr, long long a,
+                                                    long long b, long long c, const QuadLane& L,
+                                                    float* edge, int* err) {
+    QuadRows q;
+    double svb[QS];
+    int ta = L.t;
+    asm volatile("" : "+v"(ta));          // keep the LDS reads out of the callers' loops
+    const double n1 = (double)(b - a), n2 = (double)(c - b), n = n1 + n2;
+    double al, be, ga, f, k1a, k1b, k1c, k2a, k2b, k2c, w1, w2;
+    // v1 = k1a * sb + k1b * sa + k1c * sc ;  c1 = w1 * v1  (same for v2, c2)
+    if (pass == PASS_GLR) {
+        const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
+        al = al1 - al2; be = -al1; ga = al2; f = 1.0;
+        k1a = 1.0; k1b = -1.0; k1c = 0.0; w1 = -(al1 / n1);
+        k2a = -1.0; k2b = 0.0; k2c = 1.0; w2 = -(al2 / n2);
+    } else {
+        const double np = pass == PASS_RIGHT ? n2 : (pass == PASS_LEFT ? n1 : n);
+        al = pass == PASS_RIGHT ? -1.0 : (pass == PASS_LEFT ? 1.0 : 0.0);
+        be = pass == PASS_RIGHT ? 0.0 : -1.0;
+        ga = pass == PASS_LEFT ? 0.0 : 1.0;
+        f = 1.0 / (np - 1.0);
+        k1a = al; k1b = be; k1c = ga; w1 = -(f / np);
+        k2a = 0.0; k2b = 0.0; k2c = 0.0; w2 = 0.0;
+        al *= f; be *= f; ga *= f;          // covariance scale folded into the combine
+    }
+    quad_prefix_rows(q, svb, snap, fr, b, L, edge);
+    __builtin_amdgcn_sched_barrier(0);
+    double v1[QS], v2[QS], c1[QS], c2[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double ra = ldsRa[(s * DA + j) * 16 + ta], rc = ldsRc[(s * DA + j) * 16 + ta];
+            q.r[s][j] = fma(ga, rc, fma(be, ra, al * q.r[s][j]));
+        }
+        const double sa = ldsRa[(s * DA + D) * 16 + ta], sc = ldsRc[(s * DA + D) * 16 + ta];
+        v1[s] = fma(k1c, sc, fma(k1b, sa, k1a * svb[s]));
+        v2[s] = fma(k2c, sc, fma(k2b, sa, k2a * svb[s]));
+        c1[s] = w1 * v1[s];
+        c2[s] = w2 * v2[s];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    QuadRank1<0>::run(q, c1, v1);
+    if (pass == PASS_GLR) QuadRank1<0>::run(q, c2, v2);
+    auto form_single = [&](int mi, double (&arr)[DA]) {
+        const long long bm = __shfl(b, 16 * mi);
+        single_split_matrix(pass, ldsRa, ldsRc, snap, fr, a, bm, c, arr);
+    };
+    return quad_logdet(q, L.m, err, form_single);
+}
+
+constexpr int GW_WAVES = 4;
+constexpr int GW_TPB = GW_WAVES * WAVE;
+
+// Candidate scratch per slot k: c_i = i value, c_left = memoised left term (BIC:
+// 0.5 N1 log det S1; GLR: log det S1), c_x = right log det / finished distance.
 //
 // The kernel is one loop over "scans": a coarse scan over the candidates
 // i = minfeas, minfeas + istep, ... (CD:204-221) and, after a positive one, a
 // fine scan over single-frame steps around the maximum (CD:235-251).  Both kinds
-// share one body, so the two 39x39 elimination routines exist once in the code.
+// share one body, so the elimination code exists once.
 __global__ __launch_bounds__(GW_TPB) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ snap_all, double* __restrict__ cand_all,
@@ -177,26 +363,26 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
         double* __restrict__ det_start, double* __restrict__ det_maxi, double* __restrict__ det_d,
         double* __restrict__ final_start, spkd_cand_log* clog, long long log_cap,
         unsigned long long* log_count, int* err) {
-    extern __shared__ double lds[];
-    double* exRa = lds;
-    double* exRc = lds + DA * DA;
-    double* slabs = lds + 2 * DA * DA;
+    __shared__ double ldsRa[QREC];
+    __shared__ double ldsRc[QREC];
+    __shared__ float xs[CD_TILE * DA];
+    __shared__ float edges[GW_WAVES * EDGE_WAVE_FLOATS];
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int li = lane > D ? D : lane;
+    const QuadLane L = quad_lane();
     const int turn = blockIdx.x;
     const TurnDesc T = turns[turn];
     const long long n = T.len;
     const float* fr = frames + T.begin * D;
-    double* snap = snap_all + T.snap_off * REC;
+    double* snap = snap_all + T.snap_off * QREC;
     const long long cap = T.cand_cap;
     double* c_i = cand_all + 3 * T.cand_off;
     double* c_left = c_i + cap;
     double* c_x = c_left + cap;
-    double* slab = slabs + wave * REC;
 
-    build_prefix<GW_TPB>(fr, n, snap, (float*)slabs);
+    for (int e = tid; e < QREC; e += GW_TPB) { ldsRa[e] = 0.0; ldsRc[e] = 0.0; }
+    build_prefix<GW_TPB>(fr, n, snap, xs);
     __syncthreads();
 
     const int kind = P.kind;
@@ -239,109 +425,89 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
             F = 0;
             for (double x = fine_i0; x < endtune; x += 1) ++F;
             if (C + F > cap) { if (tid == 0) atomicOr(err, 4); break; }
+            // the fine i sequence, by repeated +1 like the reference
+            if (tid == 0) {
+                double x = fine_i0;
+                for (long long k = 0; k < F; ++k) { c_i[C + k] = x; x += 1; }
+            }
             base = C;                // fine-scan scratch sits behind the coarse slots
             count = F;
         }
         const long long a = (long long)start, c = (long long)end;
-        if (a != a_cur) { build_expanded(exRa, snap, fr, a, tid, GW_TPB); a_cur = a; }
-        if (c != c_cur) { build_expanded(exRc, snap, fr, c, tid, GW_TPB); c_cur = c; }
+        if (a != a_cur) { build_record_lds(ldsRa, snap, fr, a, xs, tid, GW_TPB); a_cur = a; }
+        if (c != c_cur) { build_record_lds(ldsRc, snap, fr, c, xs, tid, GW_TPB); c_cur = c; }
         __syncthreads();
         const double N = (double)(c - a);
-        // ---- jobs: -1 = pooled window (BIC, coarse scans only), 0..count-1 = split points
-        for (long long job = (long long)wave - 1; job < count; job += GW_WAVES) {
-            double a_[DA];
-            if (job < 0) {
-                if (kind == SPKD_BIC && !fine) {
-                    auto form = [&](double (&q)[DA]) {
-                        row_from_expanded(exRc, q);
-#pragma unroll
-                        for (int j = 0; j < DA; ++j) q[j] -= exRa[j * DA + li];
-                        cov_rows(q, N);
-                    };
-                    const double v = logdet_formed(a_, err, form);
-                    if (lane == 0) s_ldS = v;
-                }
-                continue;
-            }
-            double ik;
-            if (!fine) {
-                ik = c_i[job];
-            } else {
-                ik = fine_i0;
-                for (long long s2 = 0; s2 < job; ++s2) ik += 1;
-            }
-            const long long b = (long long)(start + ik);
-            const double n1 = (double)(b - a), n2 = (double)(c - b);
-            double qb[DA];
-            prefix_rows(qb, slab, snap, fr, b);
-            const bool need_left = fine || job >= n_memo;
-            double ld_right = 0.0, ld_left = 0.0, ld_w = 0.0, dist = 0.0;
-            if (kind == SPKD_KL2) {
+        const bool pooled = (kind == SPKD_BIC && !fine);
+        if (kind == SPKD_KL2) {
+            // one wave per split point, single-matrix layout (Gauss-Jordan inverses)
+            for (long long job = wave; job < count; job += GW_WAVES) {
+                const double ik = c_i[base + job];
+                const long long b = (long long)(start + ik);
+                const double n1 = (double)(b - a), n2 = (double)(c - b);
                 double ds[2], dp[2], mu[2];
 #pragma unroll 1
                 for (int t = 0; t < 2; ++t) {
+                    double a_[DA], r_[DA];
+                    single_prefix_rows(a_, snap, fr, b);
+                    single_rows_from_lds(t ? ldsRc : ldsRa, r_);
 #pragma unroll
-                    for (int j = 0; j < DA; ++j)
-                        a_[j] = t ? (exRc[j * DA + li] - qb[j]) : (qb[j] - exRa[j * DA + li]);
+                    for (int j = 0; j < DA; ++j) a_[j] = t ? (r_[j] - a_[j]) : (a_[j] - r_[j]);
                     const double nn = t ? n2 : n1;
                     const double mean_i = a_[D] / nn;
                     cov_rows(a_, nn);
                     kl2_lane_terms(a_, mean_i, ds[t], dp[t], mu[t]);
                 }
-                dist = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
-            } else {
-#pragma unroll 1
-                for (int t = 0; t < 3; ++t) {
-                    if (t == 1 && !need_left) continue;
-                    if (t == 2 && kind != SPKD_GLR) continue;
-                    auto form = [&](double (&q)[DA]) {
-                        if (t == 0) {
-#pragma unroll
-                            for (int j = 0; j < DA; ++j) q[j] = exRc[j * DA + li] - qb[j];
-                            cov_rows(q, n2);
-                        } else if (t == 1) {
-#pragma unroll
-                            for (int j = 0; j < DA; ++j) q[j] = qb[j] - exRa[j * DA + li];
-                            cov_rows(q, n1);
-                        } else {
-                            const double al1 = (n1 / N) / (n1 - 1.0), al2 = (n2 / N) / (n2 - 1.0);
-                            const double be1 = al1 / n1, be2 = al2 / n2;
-                            const double s1i = qb[D] - exRa[D * DA + li];
-                            const double s2i = exRc[D * DA + li] - qb[D];
-#pragma unroll
-                            for (int j = 0; j < D; ++j) {
-                                const double q1 = qb[j] - exRa[j * DA + li];
-                                const double q2 = exRc[j * DA + li] - qb[j];
-                                const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
-                                double v = fma(al2, q2, al1 * q1);
-                                v = fma(-(be1 * s1i), s1j, v);
-                                q[j] = fma(-(be2 * s2i), s2j, v);
-                            }
-                        }
-                    };
-                    const double v = logdet_formed(a_, err, form);
-                    if (t == 0) ld_right = v; else if (t == 1) ld_left = v; else ld_w = v;
-                }
+                const double dist = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
+                if (lane == 0) c_x[base + job] = dist;
             }
-            if (lane == 0) {
-                const long long slot = base + job;
-                if (fine) c_i[slot] = ik;
-                if (kind == SPKD_BIC) {
-                    // left term: 0.5 N1 log det S1, memoised per i inside an epoch (CD:84-90)
-                    if (need_left) c_left[slot] = 0.5 * n1 * ld_left;   // fine slots: scratch only
-                    c_x[slot] = ld_right;
-                } else if (kind == SPKD_GLR) {
-                    const double l1 = need_left ? ld_left : c_left[slot];
-                    if (need_left && !fine) c_left[slot] = l1;
-                    c_x[slot] = -(N / 2.0) * ((n1 / N) * l1 + (n2 / N) * ld_right - ld_w);
-                } else {
-                    c_x[slot] = dist;
+        } else {
+            // quad jobs: job -1 = pooled window (BIC coarse scans), then groups of 4 split
+            // points; ONE call site of the elimination for all passes (code size)
+            const long long nquads = (count + 3) / 4;
+            for (long long job = (long long)wave - (pooled ? 1 : 0); job < nquads; job += GW_WAVES) {
+                const bool is_pooled = job < 0;
+                long long k = is_pooled ? 0 : 4 * job + L.m;
+                const bool valid = is_pooled ? false : (k < count);
+                k = (k < count) ? k : count - 1;
+                const long long slot = base + k;
+                const double ik = c_i[slot];
+                const long long b = is_pooled ? a : (long long)(start + ik);
+                const double n1 = (double)(b - a), n2 = (double)(c - b);
+                const bool need_left = fine || k >= n_memo;
+                const bool any_left = __any(need_left && valid);
+                double lds_[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                for (int p = 0; p < 4; ++p) {
+                    if (is_pooled != (p == PASS_POOLED)) continue;
+                    if (p == PASS_LEFT && !any_left) continue;
+                    if (p == PASS_GLR && kind != SPKD_GLR) continue;
+                    const double v = quad_split_logdet(p, ldsRa, ldsRc, snap, fr, a, b, c, L, edges + wave * EDGE_WAVE_FLOATS, err);
+                    if (p == PASS_RIGHT) lds_[0] = v; else if (p == PASS_LEFT) lds_[1] = v;
+                    else if (p == PASS_GLR) lds_[2] = v; else lds_[3] = v;
+                }
+                if (is_pooled) {
+                    if (lane == 0) s_ldS = lds_[3];
+                    continue;
+                }
+                const double ld_right = lds_[0], ld_left = lds_[1], ld_w = lds_[2];
+                if (valid && L.t == 0) {
+                    if (kind == SPKD_BIC) {
+                        // left term: 0.5 N1 log det S1, memoised per i inside an epoch (CD:84-90)
+                        if (need_left) c_left[slot] = 0.5 * n1 * ld_left;
+                        c_x[slot] = ld_right;
+                    } else {
+                        const double l1 = need_left ? ld_left : c_left[slot];
+                        if (need_left && !fine) c_left[slot] = l1;
+                        c_x[slot] = -(N / 2.0) * ((n1 / N) * l1 + (n2 / N) * ld_right - ld_w);
+                    }
                 }
             }
         }
         __syncthreads();
         // ---- finish the distances (BIC): d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
         if (kind == SPKD_BIC) {
+            if (fine) { /* s_ldS still holds the pooled term of this window */ }
             const double ldS = s_ldS;
             const double corr = pen_w * log(N);
             for (long long k = tid; k < count; k += GW_TPB) {
@@ -422,35 +588,36 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
 }
 
 // ---------------------------------------------------------------------------
+// Sliding window: every window is independent; one wave per window, row-per-lane
+// layout (this mode is not on the DIA2 path; the quad layout is used where the
+// time goes).
 constexpr int SW_WAVES = 4;
 constexpr int SW_TPB = SW_WAVES * WAVE;
 
 __global__ __launch_bounds__(SW_TPB) void k_sw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ snap_all, double* __restrict__ d_out, int* err) {
-    __shared__ double slabs[SW_WAVES][REC];
+    __shared__ float xs[CD_TILE * DA];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int turn = blockIdx.x;
     const TurnDesc T = turns[turn];
     const long long n = T.len;
     const float* fr = frames + T.begin * D;
-    double* snap = snap_all + T.snap_off * REC;
-    build_prefix<SW_TPB>(fr, n, snap, (float*)&slabs[0][0]);
+    double* snap = snap_all + T.snap_off * QREC;
+    build_prefix<SW_TPB>(fr, n, snap, xs);
     __syncthreads();
     const int kind = P.kind;
     const double winsize = P.winsize, winstep = P.winstep;
     long long W = 0;
     for (double s = 0; s + 2 * winsize <= (double)n; s += winstep) ++W;
     const long long wsz = (long long)winsize;
-    double* slab = slabs[wave];
-    const int li = lane > D ? D : lane;
     for (long long w = wave; w < W; w += SW_WAVES) {
         const long long a = (long long)((double)w * winstep);
         const long long m = a + wsz, e = a + 2 * wsz;
         double qa[DA], qm[DA], qe[DA], a_[DA];
-        prefix_rows(qa, slab, snap, fr, a);
-        prefix_rows(qm, slab, snap, fr, m);
-        prefix_rows(qe, slab, snap, fr, e);
+        single_prefix_rows(qa, snap, fr, a);
+        single_prefix_rows(qm, snap, fr, m);
+        single_prefix_rows(qe, snap, fr, e);
         const double n1 = (double)wsz, n2 = (double)wsz, N = n1 + n2;
         double r[3] = {0.0, 0.0, 0.0};
         double kl = 0.0;
@@ -512,7 +679,6 @@ __global__ __launch_bounds__(SW_TPB) void k_sw(
             }
             d_out[T.ev_off + w] = d;
         }
-        (void)li;
     }
 }
 

@@ -54,10 +54,10 @@ __device__ __forceinline__ double kl2_from_aux(const double* __restrict__ a1,
 // mu = mean_i rounded to float32.
 __device__ __forceinline__ void kl2_lane_terms(double (&a)[DA], double mean_i,
                                                double& ds, double& dp, double& mu) {
-    ds = diag_of(a);
-    const bool ok = invert_spd(a);
-    dp = diag_of(a);
-    if (!ok) dp = __builtin_nan("");
+    double out[2];
+    spd_diag_terms_fn(a, out);
+    ds = out[0];
+    dp = out[1];
     mu = (double)(float)mean_i;
 }
 
@@ -232,8 +232,11 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
     double sv[QS], svc[QS];
     const double nC = self ? 0.0 : qr_count(qrC);
     const double n = nA + nC;
-    double wa = 1.0, wc = self ? 0.0 : 1.0;
-    if (kind == SPKD_GLR && !self) {
+    // q = wa * A + wc * C with the covariance scale 1 / (n - 1) folded into the weights
+    const bool glr = (kind == SPKD_GLR && !self);
+    const double f = 1.0 / (n - 1.0);
+    double wa = f, wc = self ? 0.0 : f;
+    if (glr) {
         wa = (nA / n) / (nA - 1.0);
         wc = (nC / n) / (nC - 1.0);
     }
@@ -259,7 +262,7 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
         sv[s] = ldsA[(s * DA + D) * 16 + ta];
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (kind == SPKD_GLR && !self) {
+    if (glr) {
         double c1[QS], c2[QS];
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
@@ -269,9 +272,14 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
         QuadRank1<0>::run(q, c1, sv);
         QuadRank1<0>::run(q, c2, svc);
     } else {
+        // S = f (Q - s s^T / n): the rank-one term with the scale folded in
+        double c1[QS];
 #pragma unroll
-        for (int s = 0; s < QS; ++s) sv[s] = fma(wc, svc[s], sv[s]);
-        quad_cov(q, sv, n);
+        for (int s = 0; s < QS; ++s) {
+            sv[s] += self ? 0.0 : svc[s];
+            c1[s] = -((f / n) * sv[s]);
+        }
+        QuadRank1<0>::run(q, c1, sv);
     }
     auto form_single = [&](int mi, double (&a)[DA]) {
         single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
@@ -321,8 +329,12 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
     // of quad_pair_logdet with self = true through a per-lane pointer
     QuadRows q;
     double sv[QS];
-    quad_load_scaled(R, L.t, 1.0, q, sv);
-    quad_cov(q, sv, qr_count(R));
+    const double nR = qr_count(R), fR = 1.0 / (nR - 1.0);
+    quad_load_scaled(R, L.t, fR, q, sv);
+    double c1[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) c1[s] = -((fR / nR) * sv[s]);
+    QuadRank1<0>::run(q, c1, sv);
     auto form_single = [&](int mi, double (&a)[DA]) { single_pair_matrix(kind, recs[mi], recs[mi], true, a); };
     const double v = quad_logdet(q, L.m, err, form_single);
     if (valid && L.t == 0) ld[c] = v;
@@ -439,14 +451,22 @@ __device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
     if (y.nan_idx < x.nan_idx) x.nan_idx = y.nan_idx;
 }
 
-// One workgroup per problem.  ex is a private working copy of the expanded
-// records (summed in place as clusters merge).  Dynamic LDS: int32 ids[N + 1].
+// One workgroup per problem.  ex is a private working copy of the quad records
+// (summed in place as clusters merge).  Dynamic LDS: int32 ids[N + 1].
+//
+// The arg-min keeps a per-row cache (row minimum, its first column, first NaN
+// column); a merge only invalidates the rows whose cached column was one of the
+// two merged clusters, so an iteration costs O(N) plus a few row rescans instead
+// of an O(N^2) scan, with numpy's first-occurrence / NaN semantics intact.
+constexpr int NO_COL = 0x7fffffff;
+
 __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         double* __restrict__ ex, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double lambdac, double threshold,
         double* __restrict__ ld, double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         int32_t* __restrict__ alive, double* __restrict__ tmp,
+        double* __restrict__ rmin_all, int32_t* __restrict__ rcache_all,
         int32_t* __restrict__ out_n, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
         double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
         double* __restrict__ final_max, double* __restrict__ final_min, int* err) {
@@ -456,7 +476,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     __shared__ ArgMin best;
     __shared__ int s_cnt[2];
     __shared__ int s_nids;
-    __shared__ double s_tmax[AHC_WAVES + 1];
+    __shared__ double s_tmax[AHC_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
     const int p = blockIdx.x;
@@ -466,29 +486,52 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     int32_t* al = alive + off;
     double* ldp = ld + off;
     double* tp = tmp + off;
-    for (long long c = tid; c < N; c += AHC_TPB) al[c] = 1;
+    double* rmin = rmin_all + off;
+    int32_t* rarg = rcache_all + 3 * off;
+    int32_t* rnan = rarg + N;
+    int32_t* dirty = rnan + N;
+    for (long long c = tid; c < N; c += AHC_TPB) { al[c] = 1; dirty[c] = 1; }
     __syncthreads();
     long long m = N;
     int n_merges = 0;
     const long long INF_IDX = 0x7fffffffffffffffLL;
-    double fmax = 0.0, fmin = 0.0;
+    double fmin = 0.0;
     while (true) {
-        // ---- 1. min / argmin over the alive sub-matrix, numpy semantics: first
-        // occurrence in row-major order; any NaN -> min is NaN and argmin the first
-        // NaN (distances.min(), distances.argmin(): CL1:203-204).  Wave per row.
-        ArgMin mine;
-        mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
-        double tmax = -__builtin_huge_val();
+        // ---- 0. refresh the cache of the rows a merge invalidated (wave per row)
         for (long long r = wave; r < N; r += AHC_WAVES) {
-            if (!al[r]) continue;
+            if (!al[r] || !dirty[r]) continue;
             const double* row = Dm + r * N;
+            double mv = __builtin_huge_val();
+            int mc = NO_COL, nc = NO_COL;
             for (long long c = lane; c < N; c += WAVE) {
                 if (!al[c]) continue;
                 const double v = row[c];
+                if (v != v) { if ((int)c < nc) nc = (int)c; continue; }
+                if (v < mv || (v == mv && (int)c < mc)) { mv = v; mc = (int)c; }
+            }
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const double v2 = __shfl_xor(mv, s);
+                const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+                if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+                nc = n2 < nc ? n2 : nc;
+            }
+            if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; dirty[r] = 0; }
+        }
+        __syncthreads();
+        // ---- 1. min / argmin over the alive sub-matrix, numpy semantics: first
+        // occurrence in row-major order; any NaN -> min is NaN and argmin the first
+        // NaN (distances.min(), distances.argmin(): CL1:203-204)
+        ArgMin mine;
+        mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+        for (long long r = tid; r < N; r += AHC_TPB) {
+            if (!al[r]) continue;
+            const double v = rmin[r];
+            const int c = rarg[r], nc = rnan[r];
+            if (nc != NO_COL) { const long long l = r * N + nc; if (l < mine.nan_idx) mine.nan_idx = l; }
+            if (c != NO_COL) {
                 const long long l = r * N + c;
-                if (v != v) { if (l < mine.nan_idx) mine.nan_idx = l; continue; }
                 if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
-                tmax = v > tmax ? v : tmax;
             }
         }
 #pragma unroll
@@ -496,23 +539,18 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             ArgMin o;
             o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
             argmin_merge(mine, o);
-            const double t2 = __shfl_xor(tmax, s);
-            tmax = t2 > tmax ? t2 : tmax;
         }
-        if (lane == 0) { red[wave] = mine; s_tmax[wave] = tmax; }
+        if (lane == 0) red[wave] = mine;
         __syncthreads();
         if (tid == 0) {
             ArgMin b = red[0];
-            double mx = s_tmax[0];
-            for (int w = 1; w < AHC_WAVES; ++w) { argmin_merge(b, red[w]); mx = s_tmax[w] > mx ? s_tmax[w] : mx; }
+            for (int w = 1; w < AHC_WAVES; ++w) argmin_merge(b, red[w]);
             best = b;
-            s_tmax[AHC_WAVES] = mx;
         }
         __syncthreads();
         const bool has_nan = best.nan_idx != INF_IDX;
         const double mind = has_nan ? __builtin_nan("") : best.v;
         const long long index = has_nan ? best.nan_idx : best.idx;
-        fmax = has_nan ? __builtin_nan("") : s_tmax[AHC_WAVES];
         fmin = mind;
         const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
         if (!go) break;
@@ -590,44 +628,86 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             }
         }
         __syncthreads();
-        // ---- 4. finish the distances, update row (and column) sa
+        // ---- 4. finish the distances, update row (and column) sa and the row caches
         double wmax = __builtin_nan(""), wmin = __builtin_nan("");
-        if (kind == SPKD_KL2) {
-            for (long long c = wave; c < N; c += AHC_WAVES) {
-                if (c == sa || !al[c]) continue;
-                const double d = kl2_from_aux(aux + (off + sa) * AUX, aux + (off + c) * AUX);
-                if (lane == 0) {
-                    Dm[sa * N + c] = d;
-                    if (variant == 1) Dm[c * N + sa] = d;
+        const double ldA = ldp[sa];
+        for (long long c = tid; c < N; c += AHC_TPB) {
+            if (c == sa || !al[c]) continue;
+            double d;
+            if (kind == SPKD_KL2) {
+                // (one lane per pair here: 39-term sums done serially)
+                const double* a1 = aux + (off + sa) * AUX;
+                const double* a2 = aux + (off + c) * AUX;
+                double t1 = 0.0, t2 = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    const float dm = (float)a1[2 * DA + i] - (float)a2[2 * DA + i];
+                    const double delta = (double)dm;
+                    t1 += (a1[i] - a2[i]) * (a2[DA + i] - a1[DA + i]);
+                    t2 += ((a1[DA + i] + a2[DA + i]) * delta) * delta;
                 }
-                if (stat_valid(d)) {
-                    wmax = (wmax != wmax || d > wmax) ? d : wmax;
-                    wmin = (wmin != wmin || d < wmin) ? d : wmin;
-                }
-            }
-        } else {
-            const double ldA = ldp[sa];
-            for (long long c = tid; c < N; c += AHC_TPB) {
-                if (c == sa || !al[c]) continue;
+                d = 0.5 * t1 + 0.5 * t2;
+            } else {
                 const double nC = qr_count(ex + (off + c) * QREC);
-                const double d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
-                Dm[sa * N + c] = d;
-                if (variant == 1) Dm[c * N + sa] = d;
+                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
+            }
+            Dm[sa * N + c] = d;
+            const int ra = rarg[c], rn = rnan[c];
+            if (variant == 1) {
+                Dm[c * N + sa] = d;
+                if (ra == sa || ra == sb || rn == sa || rn == sb) dirty[c] = 1;
+                else if (d != d) { if ((int)sa < rn) rnan[c] = (int)sa; }
+                else if (d < rmin[c] || (d == rmin[c] && (int)sa < ra)) { rmin[c] = d; rarg[c] = (int)sa; }
                 if (stat_valid(d)) {
                     wmax = (wmax != wmax || d > wmax) ? d : wmax;
                     wmin = (wmin != wmin || d < wmin) ? d : wmin;
                 }
+            } else {
+                if (ra == sb || rn == sb) dirty[c] = 1;   // column sa keeps its stale value (A-9)
             }
         }
+        if (tid == 0) dirty[sa] = 1;
         if (variant == 1) {
-            if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
-            if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const double x = __shfl_xor(wmax, s), n2 = __shfl_xor(wmin, s);
+                if (x == x && (wmax != wmax || x > wmax)) wmax = x;
+                if (n2 == n2 && (wmin != wmin || n2 < wmin)) wmin = n2;
+            }
+            if (lane == 0) {
+                if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
+                if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
+            }
         }
         __syncthreads();
     }
+    // max over the final alive sub-matrix (variant 2 reports distances.max()); NaN propagates
+    double tmax = -__builtin_huge_val();
+    bool anynan = false;
+    for (long long r = wave; r < N; r += AHC_WAVES) {
+        if (!al[r]) continue;
+        const double* row = Dm + r * N;
+        for (long long c = lane; c < N; c += WAVE) {
+            if (!al[c]) continue;
+            const double v = row[c];
+            if (v != v) anynan = true; else tmax = v > tmax ? v : tmax;
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double t2 = __shfl_xor(tmax, s);
+        tmax = t2 > tmax ? t2 : tmax;
+    }
+    anynan = __any(anynan);
+    if (lane == 0) s_tmax[wave] = anynan ? __builtin_nan("") : tmax;
+    __syncthreads();
     if (tid == 0) {
+        double mx = s_tmax[0];
+        for (int w = 1; w < AHC_WAVES; ++w) {
+            const double x = s_tmax[w];
+            if (mx == mx) mx = (x != x) ? x : (x > mx ? x : mx);
+        }
         out_n[p] = n_merges;
-        final_max[p] = fmax;
+        final_max[p] = mx;
         final_min[p] = fmin;
     }
 }

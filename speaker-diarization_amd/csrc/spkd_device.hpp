@@ -273,6 +273,21 @@ __device__ __forceinline__ double wave_sum39(double v) {
 // ---------------------------------------------------------------------------
 constexpr int ERR_NONFINITE = 1;
 
+// Out-of-line slow paths.  The straight-line eliminations are several thousand
+// instructions each; inlining the rarely taken ones at every call site blows the
+// kernels far past the instruction cache (k_gw was > 500 KB of code), so they are
+// real functions, emitted once per code object, taking the row array by pointer.
+__device__ __noinline__ double logdet_pivoted_fn(const double* rows, int* err) {
+    double a[DA];
+#pragma unroll
+    for (int j = 0; j < DA; ++j) a[j] = rows[j];
+    if (!rows_finite(a)) {
+        if (lane_id() == 0) atomicOr(err, ERR_NONFINITE);
+        return __builtin_nan("");
+    }
+    return log(det_pivoted(a));
+}
+
 template <class Form>
 __device__ __forceinline__ double logdet_formed(double (&a)[DA], int* err, Form form) {
     form(a);
@@ -283,9 +298,22 @@ __device__ __forceinline__ double logdet_formed(double (&a)[DA], int* err, Form 
     double det;
     if (!det_nopivot(a, det)) {
         form(a);
-        det = det_pivoted(a);
+        return logdet_pivoted_fn(a, err);
     }
     return log(det);
+}
+
+// out[0] = S_ii, out[1] = (S^-1)_ii (NaN if S is not positive definite), for the
+// lane's row of the covariance held in rows[] (row-per-lane layout)
+__device__ __noinline__ void spd_diag_terms_fn(const double* rows, double* out) {
+    double a[DA];
+#pragma unroll
+    for (int j = 0; j < DA; ++j) a[j] = rows[j];
+    out[0] = diag_of(a);
+    const bool ok = invert_spd(a);
+    double dp = diag_of(a);
+    if (!ok) dp = __builtin_nan("");
+    out[1] = dp;
 }
 
 }  // namespace spkd

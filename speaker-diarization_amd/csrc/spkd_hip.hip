@@ -151,8 +151,6 @@ spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
             return SPKD_EHIP;
         }
     // kernels that need more than 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)(GW_LDS_DOUBLES * sizeof(double)));
     *out = c;
     return SPKD_OK;
 }
@@ -398,17 +396,19 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     for (int64_t p = 0; p < n_prob; ++p) n_max = std::max<int64_t>(n_max, h_seg_off[p + 1] - h_seg_off[p]);
     // outputs + per-slot scratch
     void* op = nullptr;
-    const size_t out_bytes = (size_t)n_total * (2 * sizeof(int32_t) + 2 * sizeof(double) + sizeof(int32_t)) +
+    const size_t out_bytes = (size_t)n_total * (6 * sizeof(int32_t) + 3 * sizeof(double)) +
                              (size_t)n_prob * (sizeof(int32_t) + 2 * sizeof(double)) + 64;
     if ((st = scratch(c, S_AHC_OUT, out_bytes, &op)) != SPKD_OK) return st;
     double* d_merge_d = (double*)op;
     double* d_tmp = d_merge_d + n_total;
-    double* d_fmax = d_tmp + n_total;
+    double* d_rmin = d_tmp + n_total;
+    double* d_fmax = d_rmin + n_total;
     double* d_fmin = d_fmax + n_prob;
     int32_t* d_a = (int32_t*)(d_fmin + n_prob);
     int32_t* d_b = d_a + n_total;
     int32_t* d_alive = d_b + n_total;
-    int32_t* d_n = d_alive + n_total;
+    int32_t* d_rcache = d_alive + n_total;           // 3 ints per record: arg col, NaN col, dirty
+    int32_t* d_n = d_rcache + 3 * n_total;
     const size_t lds = (size_t)(n_max + 4) * sizeof(int32_t);
     if (lds > 150 * 1024) return fail(c, SPKD_EINVAL, "clustering problem too large for one workgroup's LDS");
     if (lds > 48 * 1024)
@@ -417,7 +417,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
           hipLaunchKernelGGL(k_ahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
                              B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                              P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
-                             d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
+                             d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
     HIPCHK(c, hipGetLastError());
     std::vector<unsigned long long> kmax((size_t)n_prob), kmin((size_t)n_prob);
     std::vector<double> fmax((size_t)n_prob), fmin((size_t)n_prob);
@@ -506,7 +506,7 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     TurnDesc* d_turns = nullptr;
     void *d_snap, *d_cand, *d_i32a, *d_i32b, *d_d0, *d_d1, *d_d2, *d_d3, *d_d4, *d_log;
     if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
-    if ((st = scratch(c, S_SNAP, (size_t)n_snap * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_SNAP, (size_t)n_snap * QREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
     if ((st = scratch(c, S_CAND, (size_t)n_cand * 3 * sizeof(double), &d_cand)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32A, (size_t)n_turns * sizeof(int32_t), &d_i32a)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32B, (size_t)n_ev * sizeof(int32_t), &d_i32b)) != SPKD_OK) return st;
@@ -518,7 +518,7 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if ((st = scratch(c, S_LOG, (size_t)std::max<int64_t>(log_cap, 1) * sizeof(spkd_cand_log), &d_log)) != SPKD_OK) return st;
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
     TIMED(c, SPKD_T_GW,
-          hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_DOUBLES * sizeof(double), c->stream,
+          hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), 0, c->stream,
                              d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
                              (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
                              (double*)d_d3, (double*)d_d4, (spkd_cand_log*)d_log, (long long)log_cap,
@@ -564,7 +564,7 @@ spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     TurnDesc* d_turns = nullptr;
     void *d_snap, *d_out;
     if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
-    if ((st = scratch(c, S_SNAP, (size_t)n_snap * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_SNAP, (size_t)n_snap * QREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_D0, (size_t)n_d * sizeof(double), &d_out)) != SPKD_OK) return st;
     TIMED(c, SPKD_T_SW,
           hipLaunchKernelGGL(k_sw, dim3((unsigned)n_turns), dim3(SW_TPB), 0, c->stream,

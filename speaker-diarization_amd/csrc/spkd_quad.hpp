@@ -27,6 +27,15 @@ __device__ __forceinline__ double bcast16(double v) {
     return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, x, 0x150 + K, 0xf, 0xf, true));
 }
 
+// 1 / x to ~1 ulp: hardware estimate + two Newton steps (5 instructions instead of the
+// ~15 of an IEEE division; the multipliers are not part of any parity contract)
+__device__ __forceinline__ double fast_recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 template <int K>
 struct QuadStep {
     static __device__ __forceinline__ void run(QuadRows& q, double& det, bool& ok) {
@@ -34,7 +43,7 @@ struct QuadStep {
         const double piv = bcast16<T>(q.r[S][K]);
         ok = ok && (piv > 0.0) && (piv < __builtin_huge_val());
         det *= piv;
-        const double inv = 1.0 / piv;
+        const double inv = fast_recip(piv);
         double l[QS];
 #pragma unroll
         for (int s = S; s < QS; ++s) l[s] = -(q.r[s][K] * inv);
@@ -155,6 +164,7 @@ __device__ __forceinline__ bool quad_finite(const QuadRows& q, int m) {
     for (int s = 0; s < QS; ++s)
 #pragma unroll
         for (int j = 0; j < D; ++j) ok = ok && (fabs(q.r[s][j]) < __builtin_huge_val());
+    ok = ok || ((lane_id() & 15) >= QL);        // padding lanes carry no rows
     const unsigned long long bad = __ballot(!ok);
     return ((bad >> (16 * m)) & 0xffffull) == 0ull;
 }
@@ -165,10 +175,11 @@ __device__ __forceinline__ bool quad_finite(const QuadRows& q, int m) {
 // Non-finite matrices raise ERR_NONFINITE and give NaN.
 template <class FormSingle>
 __device__ __forceinline__ double quad_logdet(QuadRows& q, int m, int* err, FormSingle form_single) {
-    const bool fin = quad_finite(q, m);
+    // a NaN / inf entry always surfaces as a pivot that is not a positive finite
+    // number, so the finite check of the reference (scipy raises ValueError) is left
+    // to the fallback, which re-forms the matrix and tests it
     double det;
-    bool ok = quad_det_nopivot(q, det);
-    ok = ok && fin;
+    const bool ok = quad_det_nopivot(q, det);
     double ld = log(det);
     const unsigned long long badmask = __ballot(!ok);
 #ifndef SPKD_NO_FALLBACK
@@ -178,13 +189,7 @@ __device__ __forceinline__ double quad_logdet(QuadRows& q, int m, int* err, Form
             if (((badmask >> (16 * mi)) & 0xffffull) == 0ull) continue;   // wave-uniform
             double a[DA];
             form_single(mi, a);
-            double v;
-            if (!rows_finite(a)) {
-                if (lane_id() == 0) atomicOr(err, ERR_NONFINITE);
-                v = __builtin_nan("");
-            } else {
-                v = log(det_pivoted(a));
-            }
+            const double v = logdet_pivoted_fn(a, err);
             if (m == mi) ld = v;
         }
     }
