@@ -191,6 +191,21 @@ spkd_status spkd_ahc(spkd_ctx *ctx, const double *d_stats, const int64_t *h_seg_
                      int32_t *h_n_merges, int32_t *h_merge_a, int32_t *h_merge_b,
                      double *h_merge_d, double *h_stat_max, double *h_stat_min);
 
+/* ---------------------------------------------------------------------------
+ * (5) Host-side helpers of the boundary (no GPU work).
+ *
+ * spkd_py2_roundtrip: v[i] <- float(str(v[i])) with Python-2 str() = "%.12g":
+ * the value the next stage reads back from a recipe time this stage writes
+ * (spk-change-detection.py:59-60 -> spk-clustering.py:16-23).
+ *
+ * spkd_labels_from_merges: replays a merge log of spkd_ahc
+ * (speakers[a].extend(speakers[b]); speakers.pop(b), spk-clustering.py:216-217)
+ * and returns for each of the n initial records its final 1-based cluster index.
+ */
+void spkd_py2_roundtrip(double *h_values, int64_t n);
+spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t *h_a,
+                                    const int32_t *h_b, int32_t *h_labels);
+
 #ifdef __cplusplus
 }
 #endif

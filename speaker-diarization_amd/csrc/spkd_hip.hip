@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -573,6 +574,35 @@ spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if (n_d > 0)
         HIPCHK(c, hipMemcpyAsync(h_d, d_out, (size_t)n_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return end_call(c);
+}
+
+// ------------------------------------------------------------------ (5) host helpers
+void spkd_py2_roundtrip(double* v, int64_t n) {
+    char buf[64];
+    for (int64_t i = 0; i < n; ++i) {
+        std::snprintf(buf, sizeof buf, "%.12g", v[i]);
+        v[i] = std::strtod(buf, nullptr);
+    }
+}
+
+spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t* h_a, const int32_t* h_b,
+                                    int32_t* h_labels) {
+    if (n < 0 || n_merges < 0 || (n > 0 && !h_labels) || (n_merges > 0 && (!h_a || !h_b))) return SPKD_EINVAL;
+    // cluster_of[i]: position (in the shrinking list) of record i's cluster
+    std::vector<int32_t> pos((size_t)n);
+    for (int64_t i = 0; i < n; ++i) pos[(size_t)i] = (int32_t)i;
+    int64_t m = n;
+    for (int64_t k = 0; k < n_merges; ++k) {
+        const int32_t a = h_a[k], b = h_b[k];
+        if (a < 0 || b <= a || b >= m) return SPKD_EINVAL;
+        for (int64_t i = 0; i < n; ++i) {
+            int32_t& p = pos[(size_t)i];
+            if (p == b) p = a; else if (p > b) --p;
+        }
+        --m;
+    }
+    for (int64_t i = 0; i < n; ++i) h_labels[i] = pos[(size_t)i] + 1;
+    return SPKD_OK;
 }
 
 }  // extern "C"

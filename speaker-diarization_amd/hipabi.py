@@ -20,7 +20,8 @@ EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_destroy', 'spkd_last_error',
            'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
            'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw',
-           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc']
+           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
+           'spkd_labels_from_merges']
 
 
 class CdParams(C.Structure):
@@ -84,6 +85,9 @@ def load_library(path=None):
     lib.spkd_sw_window_count.restype = i64
     lib.spkd_sw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp]
     lib.spkd_ahc.argtypes = [vp, vp, vp, i64, P(AhcParams), vp, vp, vp, vp, vp, vp]
+    lib.spkd_py2_roundtrip.argtypes = [vp, i64]
+    lib.spkd_py2_roundtrip.restype = None
+    lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
     if lib.spkd_abi_version() != 1:
         raise ImportError('libspkd_hip.so ABI version mismatch')
     if path is None:
@@ -93,6 +97,24 @@ def load_library(path=None):
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def py2_roundtrip(values):
+    """float(str(v)) with Python-2 str() for an array of values (host helper)."""
+    v = np.ascontiguousarray(values, dtype=np.float64).copy()
+    if v.size:
+        load_library().spkd_py2_roundtrip(_ptr(v), v.size)
+    return v
+
+
+def labels_from_merges(n, a, b):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    out = np.zeros(n, dtype=np.int32)
+    st = load_library().spkd_labels_from_merges(n, len(a), _ptr(a), _ptr(b), _ptr(out))
+    if st != SPKD_OK:
+        raise SpkdError(st, 'bad merge log')
+    return out
 
 
 class Context(object):
@@ -174,9 +196,10 @@ class Context(object):
         b = np.ascontiguousarray(begins, dtype=np.int64)
         e = np.ascontiguousarray(ends, dtype=np.int64)
         nt = len(b)
-        caps = [self.lib.spkd_gw_event_capacity(int(e[t] - b[t]), params.rate) for t in range(nt)]
-        if any(c < 0 for c in caps):
+        if not params.rate >= 10.0:
             raise SpkdError(SPKD_EINVAL, 'unsupported frame rate for the growing window (needs >= 10)')
+        # == spkd_gw_event_capacity(len, rate), vectorised
+        caps = ((e - b).astype(np.float64) / (0.2 * params.rate)).astype(np.int64) + 8
         off = np.zeros(nt + 1, dtype=np.int64)
         off[1:] = np.cumsum(caps)
         nev = int(off[-1])

@@ -20,11 +20,6 @@ DIA2_CD = dict(kind='BIC', lambdac=1.0, threshold=0.0, winsize_s=1.0, winstep_s=
 DIA2_CL = dict(variant=1, kind='BIC', lambdac=1.3, threshold=0.0, max_spk=0)
 
 
-def _roundtrip(values):
-    """float(str(x)) with Python-2 str(): what the next stage reads back."""
-    return [float(py2_float_str(v)) for v in values]
-
-
 class BatchFile(object):
     """One file of a batch: frame window in the resident array + its VAD turns
     (start / end seconds as the VAD recipe states them)."""
@@ -39,65 +34,79 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     """Returns, per file, the list of (start_s, end_s) the change-detection recipe
     would contain (already passed through the 12-digit text round trip)."""
     rate = float(rate)
-    tb, te, owner, lna0, lna1 = [], [], [], [], []
-    for fi, f in enumerate(files):
-        for (s, e) in f.vad:
-            f0 = min(int(s * rate), f.n_frames)
-            f1 = max(f0, min(int(e * rate), f.n_frames))
-            tb.append(f.frame_off + f0); te.append(f.frame_off + f1)
-            owner.append(fi); lna0.append(s); lna1.append(e)
+    nturn = [len(f.vad) for f in files]
+    if sum(nturn) == 0:
+        return [[] for _ in files]
+    vad = np.array([se for f in files for se in f.vad], dtype=np.float64).reshape(-1, 2)
+    owner = np.repeat(np.arange(len(files)), nturn)
+    foff = np.array([f.frame_off for f in files], dtype=np.int64)[owner]
+    fn = np.array([f.n_frames for f in files], dtype=np.int64)[owner]
+    ls, le = vad[:, 0], vad[:, 1]
+    f0 = np.minimum((ls * rate).astype(np.int64), fn)            # int() truncation + slice clamp
+    f1 = np.maximum(f0, np.minimum((le * rate).astype(np.int64), fn))
+    tb, te = foff + f0, foff + f1
     p = hipabi.CdParams(hipabi.KINDS[cd['kind']], 0, cd['lambdac'], cd['threshold'],
                         float(np.floor(cd['winsize_s'] * rate)), float(np.floor(cd['winstep_s'] * rate)),
                         float(np.floor(rate * cd['deltaws_s'])), rate)
     r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096)
     if timings is not None:
         timings.setdefault('gw', []).append(ctx.last_ms('gw'))
-        timings['gw_frames'] = int(sum(y - x for x, y in zip(tb, te)))
+        timings['gw_frames'] = int((te - tb).sum())
         timings['gw_windows'] = int(r['n_win'].sum())
     if r['status'] == hipabi.SPKD_ENONFINITE:
         raise ValueError('array must not contain infs or NaNs')
     off = r['off']
-    out = [[] for _ in files]
-    for t in range(len(tb)):
-        o = int(off[t])
-        nd = int(r['win_det'][o:o + int(r['n_win'][t])].sum())
-        ls, le = lna0[t], lna1[t]
-        starts = r['det_start'][o:o + nd]
-        ends = starts + r['det_maxi'][o:o + nd]
-        vals = []
-        for k in range(nd):
-            vals.append(starts[k] / rate + ls)
-            vals.append(ends[k] / rate + ls)
-        vals.append(float(r['final_start'][t]) / rate + ls)
-        vals.append(((le - ls) * rate) / rate + ls)
-        rt = _roundtrip(vals)
-        lines = out[owner[t]]
-        for k in range(nd + 1):
-            lines.append((rt[2 * k], rt[2 * k + 1]))
-    return out
+    nt = len(tb)
+    caps = np.diff(off)
+    turn_of = np.repeat(np.arange(nt), caps)
+    within = (np.arange(int(off[-1])) - off[turn_of]) < r['n_win'][turn_of]
+    nd = np.bincount(turn_of[within & (r['win_det'] == 1)], minlength=nt)     # detections per turn
+    # detection j of turn t sits at off[t] + j
+    tot = int(nd.sum())
+    det_turn = np.repeat(np.arange(nt), nd)
+    first = np.cumsum(nd) - nd
+    idx = off[det_turn] + (np.arange(tot) - first[det_turn])
+    d_start = r['det_start'][idx]
+    d_end = d_start + r['det_maxi'][idx]
+    # values in recipe order: per turn its detections, then the tail line
+    n_lines = nd + 1
+    line_turn = np.repeat(np.arange(nt), n_lines)
+    lfirst = np.cumsum(n_lines) - n_lines
+    is_tail = (np.arange(int(n_lines.sum())) - lfirst[line_turn]) == nd[line_turn]
+    t0 = np.empty(len(line_turn)); t1 = np.empty(len(line_turn))
+    t0[~is_tail] = d_start / rate + ls[det_turn]
+    t1[~is_tail] = d_end / rate + ls[det_turn]
+    t0[is_tail] = r['final_start'] / rate + ls
+    t1[is_tail] = ((le - ls) * rate) / rate + ls
+    rt = hipabi.py2_roundtrip(np.stack([t0, t1], axis=1).ravel()).reshape(-1, 2)
+    line_file = owner[line_turn]
+    bounds = np.searchsorted(line_file, np.arange(len(files) + 1))
+    return [rt[bounds[i]:bounds[i + 1]] for i in range(len(files))]
 
 
 def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=DIA2_CL, timings=None):
-    """segments: per file, [(start_s, end_s)] as the clustering script parses
-    them.  Returns per file (labels[list of int, 1-based, per segment in input
+    """segments: per file, array [(start_s, end_s)] as the clustering script parses
+    them.  Returns per file (labels[int array, 1-based, per segment in input
     order], merges[(a, b, d)])."""
     rate = float(rate)
-    b, e = [], []
-    seg_off = [0]
-    for f, segs in zip(files, segments):
-        for (s, t) in segs:
-            a0 = max(0, min(int(s * rate), f.n_frames))
-            a1 = max(a0, min(int(t * rate), f.n_frames))
-            b.append(f.frame_off + a0); e.append(f.frame_off + a1)
-        seg_off.append(len(b))
-    n = len(b)
+    cnt = [len(s) for s in segments]
+    seg_off = np.zeros(len(files) + 1, dtype=np.int64)
+    seg_off[1:] = np.cumsum(cnt)
+    n = int(seg_off[-1])
+    allseg = np.concatenate([np.asarray(s, dtype=np.float64).reshape(-1, 2) for s in segments]) if n else np.zeros((0, 2))
+    owner = np.repeat(np.arange(len(files)), cnt)
+    foff = np.array([f.frame_off for f in files], dtype=np.int64)[owner]
+    fn = np.array([f.n_frames for f in files], dtype=np.int64)[owner]
+    a0 = np.clip((allseg[:, 0] * rate).astype(np.int64), 0, fn)
+    a1 = np.maximum(a0, np.clip((allseg[:, 1] * rate).astype(np.int64), 0, fn))
+    b, e = foff + a0, foff + a1
     d_stats = ctx.dev_alloc(max(n, 1) * hipabi.REC * 8)
     try:
         ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
         if timings is not None:
             timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
             timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
-            timings['stats_frames'] = int(sum(y - x for x, y in zip(b, e)))
+            timings['stats_frames'] = int((e - b).sum())
             timings['stats_sets'] = n
         p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], 0,
                              cl['lambdac'], cl['threshold'])
@@ -105,31 +114,22 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
         if timings is not None:
             for k in ('cluster_prep', 'matrix', 'ahc'):
                 timings.setdefault(k, []).append(ctx.last_ms(k))
-            npb = np.diff(np.asarray(seg_off, dtype=np.int64))
+            npb = np.diff(seg_off)
             nm = r['n_merges'].astype(np.int64)
             timings['matrix_pairs'] = int((npb * (npb - 1) // 2).sum())
-            # merge m of a problem with N records recomputes N - 1 - (m + 1) distances
-            timings['ahc_pairs'] = int(sum(int(nm[i]) * (int(npb[i]) - 1) - int(nm[i]) * (int(nm[i]) + 1) // 2
-                                           for i in range(len(npb))))
+            # merge m of a problem with N records recomputes N - 2 - m distances
+            timings['ahc_pairs'] = int((nm * (npb - 2) - nm * (nm - 1) // 2).sum())
     finally:
         ctx.dev_free(d_stats)
     if r['status'] == hipabi.SPKD_ENONFINITE:
         raise ValueError('array must not contain infs or NaNs')
     out = []
     for fi in range(len(files)):
-        o, cnt = seg_off[fi], seg_off[fi + 1] - seg_off[fi]
-        clusters = [[k] for k in range(cnt)]
-        merges = []
-        for m in range(int(r['n_merges'][fi])):
-            a, bb, d = int(r['a'][o + m]), int(r['b'][o + m]), float(r['d'][o + m])
-            merges.append((a, bb, d))
-            clusters[a].extend(clusters[bb])
-            clusters.pop(bb)
-        labels = [0] * cnt
-        for k, members in enumerate(clusters):
-            for s in members:
-                labels[s] = k + 1
-        out.append((labels, merges))
+        o, c = int(seg_off[fi]), cnt[fi]
+        nm = int(r['n_merges'][fi])
+        a, bb, d = r['a'][o:o + nm], r['b'][o:o + nm], r['d'][o:o + nm]
+        labels = hipabi.labels_from_merges(c, a, bb)
+        out.append((labels, list(zip(a.tolist(), bb.tolist(), d.tolist()))))
     return out
 
 
@@ -140,6 +140,7 @@ def diarize_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, cl
     res = cluster_batch(ctx, d_frames, total_frames, files, segs, rate, cl, timings)
     out = []
     for s, (labels, _) in zip(segs, res):
-        order = sorted(range(len(s)), key=lambda k: (s[k][0] * rate, s[k][1] * rate, k))
-        out.append([(s[k][0], s[k][1], labels[k]) for k in order])
+        # recipe order of spk_cluster_hi's output: sorted by (start*rate, end*rate, line)
+        order = np.lexsort((np.arange(len(s)), s[:, 1] * rate, s[:, 0] * rate)) if len(s) else []
+        out.append([(float(s[k, 0]), float(s[k, 1]), int(labels[k])) for k in order])
     return out
