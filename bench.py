@@ -35,7 +35,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--files', type=int, default=64, help='1 h files per GPU per step')
+    ap.add_argument('--files', type=int, default=256, help='1 h files per GPU per step')
     ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic sessions (tiled to --files)')
     ap.add_argument('--seconds', type=float, default=3600.0)
     ap.add_argument('--speakers', type=int, default=4)

@@ -44,20 +44,26 @@ __device__ __forceinline__ void quse_decode(int e, int& idx, int& i, int& j) {
 }
 
 // Phase 1: snapshots snap[k] = moments of turn frames [0, G*k), k = 0 .. len / G.
+// Thread (row i, column group g) owns the entries (i, g + 6 m), m = 0..6: per frame
+// it reads x_i once and one x_j per entry from the LDS tile (already converted to
+// double when staged), i.e. 8 LDS reads + 7 FMAs per frame.  Sums are in frame order.
+constexpr int P1_GROUPS = 6;
+constexpr int P1_COLS = (DA + P1_GROUPS - 1) / P1_GROUPS;     // 7
+
 template <int TPB>
 __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long long n,
-                                             double* __restrict__ snap, float* xs) {
-    constexpr int EPT = (QUSE + TPB - 1) / TPB;
+                                             double* __restrict__ snap, double* xs) {
+    static_assert(TPB >= D * P1_GROUPS, "phase 1 needs 234 threads");
     const int tid = threadIdx.x;
-    int eidx[EPT], er[EPT], ec[EPT];
-    double acc[EPT];
+    const bool on = tid < D * P1_GROUPS;
+    const int i = on ? tid % D : 0, g = on ? tid / D : 0;
+    const int rbase = (i / QL) * DA * 16 + (i % QL);          // + j * 16
+    double acc[P1_COLS];
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) {
-        int e = tid + TPB * m;
-        if (e >= QUSE) e = QUSE - 1;
-        quse_decode(e, eidx[m], er[m], ec[m]);
+    for (int m = 0; m < P1_COLS; ++m) {
         acc[m] = 0.0;
-        if (tid + TPB * m < QUSE) snap[eidx[m]] = 0.0;
+        const int j = g + P1_GROUPS * m;
+        if (on && j < DA) snap[rbase + j * 16] = 0.0;
     }
     if (tid == 0) snap[QREC_COUNT_AT] = 0.0;
     for (long long t0 = 0; t0 < n; t0 += CD_TILE) {
@@ -65,20 +71,25 @@ __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long 
         const float* src = fr + t0 * D;
         for (int idx = tid; idx < tl * D; idx += TPB) {
             int f = idx / D, c = idx - f * D;
-            xs[f * DA + c] = src[idx];
+            xs[f * DA + c] = (double)src[idx];
         }
-        if (tid < tl) xs[tid * DA + D] = 1.0f;
+        if (tid < tl) xs[tid * DA + D] = 1.0;
         __syncthreads();
         for (int f = 0; f < tl; ++f) {
+            const double xi = xs[f * DA + i];
 #pragma unroll
-            for (int m = 0; m < EPT; ++m)
-                acc[m] = fma((double)xs[f * DA + er[m]], (double)xs[f * DA + ec[m]], acc[m]);
+            for (int m = 0; m < P1_COLS; ++m) {
+                const int j = g + P1_GROUPS * m;
+                acc[m] = fma(xi, xs[f * DA + (j < DA ? j : 0)], acc[m]);
+            }
             const long long t = t0 + f + 1;
             if ((t % SNAP_G) == 0) {
                 double* dst = snap + (t / SNAP_G) * QREC;
 #pragma unroll
-                for (int m = 0; m < EPT; ++m)
-                    if (tid + TPB * m < QUSE) dst[eidx[m]] = acc[m];
+                for (int m = 0; m < P1_COLS; ++m) {
+                    const int j = g + P1_GROUPS * m;
+                    if (on && j < DA) dst[rbase + j * 16] = acc[m];
+                }
                 if (tid == 0) dst[QREC_COUNT_AT] = (double)t;
             }
         }
@@ -92,22 +103,22 @@ __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long 
 // Contains block-wide barriers: call from uniform control flow.
 __device__ __forceinline__ void build_record_lds(double* lds, const double* __restrict__ snap,
                                                  const float* __restrict__ fr, long long t,
-                                                 float* xs, int tid, int nthreads) {
+                                                 double* xs, int tid, int nthreads) {
     const long long k = t / SNAP_G;
     const int ne = (int)(t - k * SNAP_G);
     const float* src = fr + k * SNAP_G * D;
     for (int idx = tid; idx < ne * D; idx += nthreads) {
         const int f = idx / D, c = idx - f * D;
-        xs[f * DA + c] = src[idx];
+        xs[f * DA + c] = (double)src[idx];
     }
-    if (tid < ne) xs[tid * DA + D] = 1.0f;
+    if (tid < ne) xs[tid * DA + D] = 1.0;
     __syncthreads();
     const double* s = snap + k * QREC;
     for (int e = tid; e < QUSE; e += nthreads) {
         int idx, i, j;
         quse_decode(e, idx, i, j);
         double v = s[idx];
-        for (int f = 0; f < ne; ++f) v = fma((double)xs[f * DA + i], (double)xs[f * DA + j], v);
+        for (int f = 0; f < ne; ++f) v = fma(xs[f * DA + i], xs[f * DA + j], v);
         lds[idx] = v;
     }
     __syncthreads();
@@ -348,6 +359,9 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
 
 constexpr int GW_WAVES = 4;
 constexpr int GW_TPB = GW_WAVES * WAVE;
+constexpr int GW_EDGE_BYTES = GW_WAVES * 4 * (SNAP_G - 1) * D * 4;
+constexpr int GW_TILE_BYTES = CD_TILE * DA * 8;
+constexpr int GW_LDS_BYTES = 2 * QREC * 8 + (GW_EDGE_BYTES > GW_TILE_BYTES ? GW_EDGE_BYTES : GW_TILE_BYTES);
 
 // Candidate scratch per slot k: c_i = i value, c_left = memoised left term (BIC:
 // 0.5 N1 log det S1; GLR: log det S1), c_x = right log det / finished distance.
@@ -363,10 +377,13 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
         double* __restrict__ det_start, double* __restrict__ det_maxi, double* __restrict__ det_d,
         double* __restrict__ final_start, spkd_cand_log* clog, long long log_cap,
         unsigned long long* log_count, int* err) {
-    __shared__ double ldsRa[QREC];
-    __shared__ double ldsRc[QREC];
-    __shared__ float xs[CD_TILE * DA];
-    __shared__ float edges[GW_WAVES * EDGE_WAVE_FLOATS];
+    // dynamic LDS (GW_LDS_BYTES): Ra | Rc | per-wave edge buffers; the frame tile of
+    // phase 1 / build_record_lds aliases the edge buffers (never live together)
+    extern __shared__ double gw_lds[];
+    double* ldsRa = gw_lds;
+    double* ldsRc = gw_lds + QREC;
+    float* edges = (float*)(gw_lds + 2 * QREC);
+    double* xs = gw_lds + 2 * QREC;
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -597,7 +614,7 @@ constexpr int SW_TPB = SW_WAVES * WAVE;
 __global__ __launch_bounds__(SW_TPB) void k_sw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ snap_all, double* __restrict__ d_out, int* err) {
-    __shared__ float xs[CD_TILE * DA];
+    __shared__ double xs[CD_TILE * DA];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int turn = blockIdx.x;
     const TurnDesc T = turns[turn];

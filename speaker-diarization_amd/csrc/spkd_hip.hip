@@ -152,6 +152,8 @@ spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
             return SPKD_EHIP;
         }
     // kernels that need more than 64 KiB of dynamic LDS
+    // k_gw carves more than 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS_BYTES);
     *out = c;
     return SPKD_OK;
 }
@@ -519,7 +521,7 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if ((st = scratch(c, S_LOG, (size_t)std::max<int64_t>(log_cap, 1) * sizeof(spkd_cand_log), &d_log)) != SPKD_OK) return st;
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
     TIMED(c, SPKD_T_GW,
-          hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), 0, c->stream,
+          hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_BYTES, c->stream,
                              d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
                              (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
                              (double*)d_d3, (double*)d_d4, (spkd_cand_log*)d_log, (long long)log_cap,
