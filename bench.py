@@ -41,6 +41,9 @@ def parse():
     ap.add_argument('--speakers', type=int, default=4)
     ap.add_argument('--cpu-sample-seconds', type=float, default=420.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
+    ap.add_argument('--share-device', action='store_true',
+                    help='rehearsal only: every rank uses GPU 0 (needs --backend gloo)')
     return ap.parse_args()
 
 
@@ -85,10 +88,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     hipabi = importlib.import_module(PKG + '.hipabi')
     synth = importlib.import_module(PKG + '.synth')
     pipeline = importlib.import_module(PKG + '.pipeline')
@@ -115,8 +123,16 @@ def main():
     ctx = hipabi.Context(local, stream)
     ptr = frames.data_ptr()
 
+    distributed = importlib.import_module(PKG + '.distributed')
+
     def step(tm=None):
-        return pipeline.diarize_batch(ctx, ptr, total, files, timings=tm)
+        rows = pipeline.diarize_batch(ctx, ptr, total, files, timings=tm)
+        if world == 1:
+            return rows
+        # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)
+        local_txt = [(rank + world * i, distributed.recipe_text('file%05d.wav' % (rank + world * i), r))
+                     for i, r in enumerate(rows)]
+        return distributed.gather_texts(local_txt, dist)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,9 +150,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tdt = torch.tensor([dt], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
+        if rank == 0:
+            assert out is not None and len(out) == world * args.files, 'recipe gather incomplete'
     hours = world * args.files * (args.seconds / 3600.0) * args.steps
     value = hours / dt
 

@@ -152,3 +152,33 @@ def test_empty_and_short_turns(eng):
     assert res[1].events == [] and res[1].final_start == 0.0
     assert res[2].events == [] and res[2].final_start == 0.0
     assert [e[0] for e in res[0].events].count('win') >= 1
+
+
+def test_dropin_scripts_as_subprocesses(tmp_path):
+    """The executables spk-diarization2.py would call (./spk-change-detection.py,
+    ./spk-clustering.py; spk-diarization2.py:122-128), run as child processes with
+    its exact argv from the repository root, against the reference goldens."""
+    import subprocess
+    import sys
+    from helpers import load_cases, session
+    synth = pkg('synth')
+    cases = {c['name']: c for c in load_cases()}
+    cd, cl = cases['B_cd_gw_bic'], cases['B_cl1_hi_bic']
+    feats, _, _ = session(cd['session'])
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'meeting.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(cd['input_recipe'])
+    spkc = os.path.join(tmp, 'spkc.recipe')
+    out = os.path.join(tmp, 'out.recipe')
+    r1 = subprocess.run([sys.executable, './spk-change-detection.py', os.path.join(tmp, 'vad.recipe'),
+                         os.path.join(tmp, 'fea'), '-o', spkc, '-m', 'gw', '-d', 'BIC', '-w', '1.0',
+                         '-st', '3.0', '-dws', '0.1', '-l', '1.0'], cwd=ROOT, capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, './spk-clustering.py', spkc, os.path.join(tmp, 'fea'), '-o', out,
+                         '-m', 'hi', '-l', '1.3'], cwd=ROOT, capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert open(spkc).read() == cd['output_recipe']
+    assert open(out).read() == cl['output_recipe']
+    assert 'Merging:' in r2.stdout and 'Total detected speakers:' in r2.stdout
