@@ -130,9 +130,7 @@ def main():
         if world == 1:
             return rows
         # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)
-        local_txt = [(rank + world * i, distributed.recipe_text('file%05d.wav' % (rank + world * i), r))
-                     for i, r in enumerate(rows)]
-        return distributed.gather_texts(local_txt, dist)
+        return distributed.gather_rows([(rank + world * i, r) for i, r in enumerate(rows)], dist)
 
     def barrier():
         torch.cuda.synchronize()

@@ -153,6 +153,18 @@ spkd_status spkd_gw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
                     double *h_final_start,
                     spkd_cand_log *h_log, int64_t log_cap, int64_t *h_log_count);
 
+/* Same as spkd_gw; with check_capacity = 0 the per-turn capacity implied by
+ * h_ev_off may be smaller than spkd_gw_event_capacity() -- a turn that needs more
+ * makes the call return SPKD_EOVERFLOW (nothing is written out of bounds) and the
+ * caller repeats it with the guaranteed capacity. */
+spkd_status spkd_gw_ex(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
+                       const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
+                       const spkd_cd_params *params, const int64_t *h_ev_off, int check_capacity,
+                       int32_t *h_n_win, double *h_win_maxd, int32_t *h_win_det,
+                       double *h_det_start, double *h_det_maxi, double *h_det_d,
+                       double *h_final_start,
+                       spkd_cand_log *h_log, int64_t log_cap, int64_t *h_log_count);
+
 /* Sliding-window distances, the per-window part of dist_sw
  * (spk-change-detection.py:304-312): window w of turn t compares
  * [int(w*step), int(w*step+size)) with [int(w*step+size), int(w*step+2*size)).

@@ -489,6 +489,15 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
                     int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det, double* h_det_start,
                     double* h_det_maxi, double* h_det_d, double* h_final_start, spkd_cand_log* h_log,
                     int64_t log_cap, int64_t* h_log_count) {
+    return spkd_gw_ex(c, d_frames, n_frames, hb, he, n_turns, P, h_ev_off, 1, h_n_win, h_win_maxd, h_win_det,
+                      h_det_start, h_det_maxi, h_det_d, h_final_start, h_log, log_cap, h_log_count);
+}
+
+spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+                       const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
+                       int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
+                       double* h_det_start, double* h_det_maxi, double* h_det_d, double* h_final_start,
+                       spkd_cand_log* h_log, int64_t log_cap, int64_t* h_log_count) {
     if (!c || !P || n_turns < 0) return SPKD_EINVAL;
     if (h_log_count) *h_log_count = 0;
     if (n_turns == 0) return SPKD_OK;
@@ -501,7 +510,7 @@ spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     int64_t n_snap, n_cand;
     spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_ev_off, true, turns, n_snap, n_cand);
     if (st != SPKD_OK) return st;
-    for (int64_t t = 0; t < n_turns; ++t)
+    for (int64_t t = 0; check_capacity && t < n_turns; ++t)
         if (turns[(size_t)t].ev_cap < spkd_gw_event_capacity(turns[(size_t)t].len, P->rate))
             return fail(c, SPKD_EINVAL, "gw: event capacity too small, see spkd_gw_event_capacity");
     if ((st = begin_call(c)) != SPKD_OK) return st;

@@ -55,10 +55,19 @@ def gather_texts(local, dist=None):
     return out
 
 
+def gather_rows(local, dist=None):
+    """local: list of (file_index, float64 array [n, 3]) -> on rank 0 {file_index: array}."""
+    enc = [(i, np.ascontiguousarray(a, dtype=np.float64).tobytes().hex()) for i, a in local]
+    got = gather_texts(enc, dist)
+    if got is None:
+        return None
+    return {i: np.frombuffer(bytes.fromhex(t), dtype=np.float64).reshape(-1, 3) for i, t in got.items()}
+
+
 def recipe_text(audio, rows, lna_prefix='a'):
     """rows: [(start_s, end_s, speaker)] -> clustering-stage recipe text
     (writer grammar of spk-clustering.py:66-70, lna renamed a_1, a_2, ...)."""
     from .recipe import py2_float_str
     return ''.join('audio=%s lna=%s_%d start-time=%s end-time=%s speaker=speaker_%d\n' % (
-        audio, lna_prefix, k + 1, py2_float_str(s), py2_float_str(e), spk)
+        audio, lna_prefix, k + 1, py2_float_str(s), py2_float_str(e), int(spk))
         for k, (s, e, spk) in enumerate(rows))

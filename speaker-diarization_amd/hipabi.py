@@ -19,7 +19,7 @@ DIM = 39
 EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
            'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
-           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw',
+           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw', 'spkd_gw_ex',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
            'spkd_labels_from_merges']
 
@@ -81,6 +81,8 @@ def load_library(path=None):
     lib.spkd_gw_event_capacity.restype = i64
     lib.spkd_gw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp, vp, vp, vp, vp, vp, vp,
                             vp, i64, P(i64)]
+    lib.spkd_gw_ex.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, C.c_int, vp, vp, vp, vp, vp, vp,
+                               vp, vp, i64, P(i64)]
     lib.spkd_sw_window_count.argtypes = [i64, dbl, dbl]
     lib.spkd_sw_window_count.restype = i64
     lib.spkd_sw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp]
@@ -192,33 +194,41 @@ class Context(object):
         return self.check(st, allow=(SPKD_ENONFINITE,))
 
     # ---- (3)
-    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096):
+    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096, tight=False):
+        """tight=True sizes the event arrays for the typical case (a quarter of the
+        guaranteed bound) and transparently repeats the call with the full bound if
+        the device reports an overflow -- four times less data to allocate and copy."""
         b = np.ascontiguousarray(begins, dtype=np.int64)
         e = np.ascontiguousarray(ends, dtype=np.int64)
         nt = len(b)
         if not params.rate >= 10.0:
             raise SpkdError(SPKD_EINVAL, 'unsupported frame rate for the growing window (needs >= 10)')
         # == spkd_gw_event_capacity(len, rate), vectorised
-        caps = ((e - b).astype(np.float64) / (0.2 * params.rate)).astype(np.int64) + 8
-        off = np.zeros(nt + 1, dtype=np.int64)
-        off[1:] = np.cumsum(caps)
-        nev = int(off[-1])
-        n_win = np.zeros(nt, dtype=np.int32)
-        win_maxd = np.zeros(nev, dtype=np.float64)
-        win_det = np.zeros(nev, dtype=np.int32)
-        det_start = np.zeros(nev, dtype=np.float64)
-        det_maxi = np.zeros(nev, dtype=np.float64)
-        det_d = np.zeros(nev, dtype=np.float64)
-        final_start = np.zeros(nt, dtype=np.float64)
+        full = ((e - b).astype(np.float64) / (0.2 * params.rate)).astype(np.int64) + 8
         while True:
+            caps = (full // 4 + 8) if tight else full
+            off = np.zeros(nt + 1, dtype=np.int64)
+            off[1:] = np.cumsum(caps)
+            nev = int(off[-1])
+            n_win = np.empty(nt, dtype=np.int32)
+            win_maxd = np.empty(nev, dtype=np.float64)
+            win_det = np.empty(nev, dtype=np.int32)
+            det_start = np.empty(nev, dtype=np.float64)
+            det_maxi = np.empty(nev, dtype=np.float64)
+            det_d = np.empty(nev, dtype=np.float64)
+            final_start = np.empty(nt, dtype=np.float64)
             log = (CandLog * max(log_cap, 1))()
             cnt = C.c_int64(0)
-            st = self.lib.spkd_gw(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
-                                  C.byref(params), _ptr(off), _ptr(n_win), _ptr(win_maxd),
-                                  _ptr(win_det), _ptr(det_start), _ptr(det_maxi), _ptr(det_d),
-                                  _ptr(final_start), C.cast(log, C.c_void_p), log_cap, C.byref(cnt))
+            st = self.lib.spkd_gw_ex(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
+                                     C.byref(params), _ptr(off), 0 if tight else 1, _ptr(n_win),
+                                     _ptr(win_maxd), _ptr(win_det), _ptr(det_start), _ptr(det_maxi),
+                                     _ptr(det_d), _ptr(final_start), C.cast(log, C.c_void_p), log_cap,
+                                     C.byref(cnt))
             if st == SPKD_EOVERFLOW and cnt.value > log_cap:
                 log_cap = int(cnt.value) + 16      # the run is deterministic: retry with room
+                continue
+            if st == SPKD_EOVERFLOW and tight:
+                tight = False                      # an unusually busy turn: use the guaranteed bound
                 continue
             self.check(st, allow=(SPKD_ENONFINITE,))
             break

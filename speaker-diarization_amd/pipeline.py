@@ -48,7 +48,7 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     p = hipabi.CdParams(hipabi.KINDS[cd['kind']], 0, cd['lambdac'], cd['threshold'],
                         float(np.floor(cd['winsize_s'] * rate)), float(np.floor(cd['winstep_s'] * rate)),
                         float(np.floor(rate * cd['deltaws_s'])), rate)
-    r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096)
+    r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096, tight=True)
     if timings is not None:
         timings.setdefault('gw', []).append(ctx.last_ms('gw'))
         timings['gw_frames'] = int((te - tb).sum())
@@ -84,7 +84,8 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     return [rt[bounds[i]:bounds[i + 1]] for i in range(len(files))]
 
 
-def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=DIA2_CL, timings=None):
+def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=DIA2_CL, timings=None,
+                  want_merges=False):
     """segments: per file, array [(start_s, end_s)] as the clustering script parses
     them.  Returns per file (labels[int array, 1-based, per segment in input
     order], merges[(a, b, d)])."""
@@ -129,18 +130,21 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
         nm = int(r['n_merges'][fi])
         a, bb, d = r['a'][o:o + nm], r['b'][o:o + nm], r['d'][o:o + nm]
         labels = hipabi.labels_from_merges(c, a, bb)
-        out.append((labels, list(zip(a.tolist(), bb.tolist(), d.tolist()))))
+        out.append((labels, list(zip(a.tolist(), bb.tolist(), d.tolist())) if want_merges else None))
     return out
 
 
 def diarize_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, cl=DIA2_CL, timings=None):
-    """CD (gw/BIC) + CL (hi/BIC) for a batch; returns per file
-    [(start_s, end_s, speaker)] in recipe order."""
+    """CD (gw/BIC) + CL (hi/BIC) for a batch; returns per file an array of rows
+    [start_s, end_s, speaker] in recipe order."""
     segs = change_detect_batch(ctx, d_frames, total_frames, files, rate, cd, timings)
     res = cluster_batch(ctx, d_frames, total_frames, files, segs, rate, cl, timings)
     out = []
     for s, (labels, _) in zip(segs, res):
         # recipe order of spk_cluster_hi's output: sorted by (start*rate, end*rate, line)
-        order = np.lexsort((np.arange(len(s)), s[:, 1] * rate, s[:, 0] * rate)) if len(s) else []
-        out.append([(float(s[k, 0]), float(s[k, 1]), int(labels[k])) for k in order])
+        if len(s) == 0:
+            out.append(np.zeros((0, 3)))
+            continue
+        order = np.lexsort((np.arange(len(s)), s[:, 1] * rate, s[:, 0] * rate))
+        out.append(np.column_stack([s[order], labels[order].astype(np.float64)]))
     return out

@@ -136,7 +136,7 @@ def test_batch_pipeline_equals_file_based_scripts(tmp_path, eng):
             _, final, _, _ = _run_scripts(tmp, e2, 'hip')
             rows = re.findall(r'start-time=(\S+) end-time=(\S+) speaker=speaker_(\d+)', final)
             want = [(float(a), float(b), int(c)) for a, b, c in rows]
-            assert got[k] == want, k
+            assert [(a, b, int(c)) for a, b, c in got[k].tolist()] == want, k
     finally:
         e2.close()
 
