@@ -129,23 +129,33 @@ __device__ __forceinline__ void build_record_lds(double* lds, const double* __re
 // positions are first copied to a per-wave LDS buffer (coalesced, few registers),
 // the snapshot rows are loaded straight into the row registers, then the edge
 // frames are added in frame order (positions with fewer edge frames add zeros).
-constexpr int EDGE_FLOATS = (SNAP_G - 1) * D;          // per position
+constexpr int EDGE_FLOATS = (SNAP_G - 1) * D;          // per position (<= G/2 used since snapshots are two-sided)
 constexpr int EDGE_WAVE_FLOATS = 4 * EDGE_FLOATS;      // per wave
 
 __device__ __forceinline__ void quad_prefix_rows(QuadRows& q, double (&sv)[QS],
                                                  const double* __restrict__ snap,
                                                  const float* __restrict__ fr, long long tpos,
-                                                 const QuadLane& L, float* edge /* per-wave LDS */) {
-    const long long k = tpos / SNAP_G;
+                                                 long long nturn, const QuadLane& L,
+                                                 float* edge /* per-wave LDS */) {
+    // nearest snapshot: below (add the frames [G k, t)) or above (subtract [t, G (k+1)))
+    long long k = tpos / SNAP_G;
+    int ne = (int)(tpos - k * SNAP_G);
+    double sgn = 1.0;
+    long long first = k * SNAP_G;                 // first edge frame
+    if (ne > SNAP_G / 2 && (k + 1) * SNAP_G <= nturn) {
+        k += 1;
+        first = tpos;
+        ne = SNAP_G - ne;
+        sgn = -1.0;
+    }
     const double* s = snap + k * QREC;
-    const int ne = (int)(tpos - k * SNAP_G);
     const int lane = lane_id();
     // stage the edge frames of the four positions (contiguous floats each)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const long long km = __shfl(k, 16 * mi);
+        const long long fm = __shfl(first, 16 * mi);
         const int nem = __shfl(ne, 16 * mi);
-        const float* src = fr + km * SNAP_G * D;
+        const float* src = fr + fm * D;
         for (int idx = lane; idx < nem * D; idx += WAVE) edge[mi * EDGE_FLOATS + idx] = src[idx];
     }
 #pragma unroll
@@ -162,14 +172,15 @@ __device__ __forceinline__ void quad_prefix_rows(QuadRows& q, double (&sv)[QS],
     const bool carrier = L.t < QL;
 #pragma unroll 1
     for (int e = 0; e < mx; ++e) {
-        double x[QS];
+        double x[QS], cx[QS];
 #pragma unroll
         for (int ss = 0; ss < QS; ++ss) {
             const float xf = (carrier && e < ne) ? mine[e * D + QL * ss + (carrier ? L.t : 0)] : 0.0f;
             x[ss] = (double)xf;
-            sv[ss] += x[ss];
+            cx[ss] = sgn * x[ss];
+            sv[ss] += cx[ss];
         }
-        QuadRank1<0>::run(q, x, x);
+        QuadRank1<0>::run(q, cx, x);
     }
 }
 
@@ -307,8 +318,8 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsR
 __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsRa, const double* ldsRc,
                                                     const double* __restrict__ snap,
                                                     const float* __restrict__ fr, long long a,
-                                                    long long b, long long c, const QuadLane& L,
-                                                    float* edge, int* err) {
+                                                    long long b, long long c, long long nturn,
+                                                    const QuadLane& L, float* edge, int* err) {
     QuadRows q;
     double svb[QS];
     int ta = L.t;
@@ -331,7 +342,7 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
         k2a = 0.0; k2b = 0.0; k2c = 0.0; w2 = 0.0;
         al *= f; be *= f; ga *= f;          // covariance scale folded into the combine
     }
-    quad_prefix_rows(q, svb, snap, fr, b, L, edge);
+    quad_prefix_rows(q, svb, snap, fr, b, nturn, L, edge);
     __builtin_amdgcn_sched_barrier(0);
     double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
                     if (is_pooled != (p == PASS_POOLED)) continue;
                     if (p == PASS_LEFT && !any_left) continue;
                     if (p == PASS_GLR && kind != SPKD_GLR) continue;
-                    const double v = quad_split_logdet(p, ldsRa, ldsRc, snap, fr, a, b, c, L, edges + wave * EDGE_WAVE_FLOATS, err);
+                    const double v = quad_split_logdet(p, ldsRa, ldsRc, snap, fr, a, b, c, n, L, edges + wave * EDGE_WAVE_FLOATS, err);
                     if (p == PASS_RIGHT) lds_[0] = v; else if (p == PASS_LEFT) lds_[1] = v;
                     else if (p == PASS_GLR) lds_[2] = v; else lds_[3] = v;
                 }
