@@ -176,6 +176,17 @@ def main():
         pair_rate = 0.0
         if avg('matrix') > 0:
             pair_rate = timings.get('matrix_pairs', 0) / (avg('matrix') / 1e3)
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs; 2 x FETCH + WRITE: the gfx950 FETCH_SIZE halving was
+        # calibrated on k_chunk_stats, whose read volume is known exactly) -- only valid
+        # for the workload those passes were taken on
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01b_bench256_hbm_traffic.json')
+        if (args.files, args.seconds, args.speakers) == (256, 3600.0, 4) and os.path.exists(tfile):
+            with open(tfile) as f:
+                tk = json.load(f)['kernels'].get(dom)
+            if tk:
+                traffic = int(tk['hbm_bytes_per_launch_fetch_doubled'])
         res = {
             'metric': 'diarized audio throughput (CD gw/BIC + CL hi/BIC)',
             'value': value, 'unit': 'hours-audio/s', 'n_gpus': world, 'steps': args.steps,
@@ -191,7 +202,7 @@ def main():
                        'segments_per_step': timings.get('stats_sets', 0),
                        'parallelism': 'file-sharded x%d, no data-path collective' % world},
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None},
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic},
             'kernels': per_kernel,
             'device_ms_per_step': round(sum(v[0] for v in kernels.values()) + avg('cluster_prep') + avg('reduce_sets'), 3),
         }
