@@ -1,0 +1,115 @@
+// Micro-benchmark: one-wave-per-SIMD quad elimination (quad_pair_logdet) vs the
+// column-blocked form (two waves per SIMD) on BIC pair distances from quad records.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "spkd_cluster.hpp"
+#include "spkd_blocked.hpp"
+using namespace spkd;
+
+// BIC union covariance of (A in LDS, C in global), column by column
+struct PairSrc {
+    const double* ldsA;     // LDS quad record of A
+    const double* gC;       // global quad record of C (already + lane t)
+    int t;
+    double f, k1;           // 1/(n-1), -(f/n)
+    double sv[QS];          // sums of the union for the lane's rows
+    template <int J>
+    __device__ __forceinline__ void load(double (&col)[QS]) {
+#pragma unroll
+        for (int s = 0; s < QS; ++s) col[s] = gC[(s * DA + J) * 16];
+    }
+    template <int J>
+    __device__ __forceinline__ void finish(double (&col)[QS]) {
+        const double svj = bcast16<J % QL>(sv[J / QL]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const double q = ldsA[(s * DA + J) * 16 + t] + col[s];
+            col[s] = fma(k1 * sv[s], svj, f * q);
+        }
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(MODE == 0 ? 256 : 512) void k_pairs(const double* __restrict__ qr, int n_rec,
+                                                                   double* __restrict__ out, int* err) {
+    __shared__ double ldsA[QREC];
+    __shared__ double schur[(MODE == 0 ? 1 : 8) * SCHUR_TILE];
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const QuadLane L = quad_lane();
+    const int a = blockIdx.x % n_rec;
+    const double* A = qr + (size_t)a * QREC;
+    for (int e = threadIdx.x; e < QREC; e += blockDim.x) ldsA[e] = A[e];
+    __syncthreads();
+    const double nA = ldsA[QREC_COUNT_AT];
+    double acc = 0.0;
+    for (int base = 4 * wave; base < n_rec; base += 4 * nw) {
+        int rc = base + L.m; rc = rc < n_rec ? rc : n_rec - 1;
+        const double* C = qr + (size_t)rc * QREC;
+        if (MODE == 0) {
+            const double* recs[4]; bool selfs[4];
+            for (int mi = 0; mi < 4; ++mi) { int c = base + mi; c = c < n_rec ? c : n_rec - 1; recs[mi] = qr + (size_t)c * QREC; selfs[mi] = false; }
+            acc += quad_pair_logdet(SPKD_BIC, ldsA, nA, A, C, false, L, recs, selfs, err);
+        } else {
+            PairSrc src;
+            int ta = L.t; asm volatile("" : "+v"(ta));
+            src.ldsA = ldsA; src.gC = C + L.t; src.t = ta;
+            const double n = nA + C[QREC_COUNT_AT];
+            src.f = 1.0 / (n - 1.0); src.k1 = -(src.f / n);
+#pragma unroll
+            for (int s = 0; s < QS; ++s) src.sv[s] = ldsA[(s * DA + D) * 16 + ta] + C[(s * DA + D) * 16 + L.t];
+            bool ok;
+            acc += quad_logdet_blocked(src, schur + wave * SCHUR_TILE, L, ok);
+        }
+    }
+    if (L.t == 0) out[(size_t)blockIdx.x * 32 + wave * 4 + L.m] = acc;
+}
+
+int main(int argc, char** argv) {
+    int n_rec = argc > 1 ? atoi(argv[1]) : 387;
+    int blocks = argc > 2 ? atoi(argv[2]) : 4096;
+    std::vector<double> h((size_t)n_rec * QREC, 0.0);
+    srand(2);
+    for (int r = 0; r < n_rec; ++r) {
+        std::vector<double> M(DA * DA, 0.0);
+        const int nf = 300 + (r % 7) * 100;
+        for (int f = 0; f < nf; ++f) {
+            double x[DA];
+            for (int i = 0; i < D; ++i) x[i] = (rand() / (double)RAND_MAX) - 0.5 + 0.01 * r;
+            x[D] = 1.0;
+            for (int i = 0; i < DA; ++i) for (int j = 0; j < DA; ++j) M[j * DA + i] += x[i] * x[j];
+        }
+        double* o = &h[(size_t)r * QREC];
+        for (int i = 0; i < D; ++i) for (int j = 0; j < DA; ++j) o[qr_index(i, j)] = M[j * DA + i];
+        o[QREC_COUNT_AT] = nf;
+    }
+    double *dE, *dO0, *dO1; int* dErr;
+    hipMalloc(&dE, h.size() * 8); hipMalloc(&dO0, (size_t)blocks * 32 * 8); hipMalloc(&dO1, (size_t)blocks * 32 * 8); hipMalloc(&dErr, 4);
+    hipMemcpy(dE, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(dErr, 0, 4); hipMemset(dO0, 0, (size_t)blocks * 32 * 8); hipMemset(dO1, 0, (size_t)blocks * 32 * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 2; ++mode)
+        for (int it = 0; it < 3; ++it) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(k_pairs<0>, dim3(blocks), dim3(256), 0, 0, dE, n_rec, dO0, dErr);
+            else hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dO1, dErr);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%s: %.3f ms, %.1f M pairs/s\n", mode ? "blocked (8 waves)" : "quad    (4 waves)", ms, (double)blocks * n_rec / ms / 1e3);
+        }
+    // compare per-block sums: mode 0 has 16 slots per block, mode 1 has 32; compare block totals
+    std::vector<double> o0((size_t)blocks * 32), o1((size_t)blocks * 32);
+    hipMemcpy(o0.data(), dO0, o0.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(o1.data(), dO1, o1.size() * 8, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int b = 0; b < blocks; ++b) {
+        double s0 = 0, s1 = 0;
+        for (int i = 0; i < 32; ++i) { s0 += o0[(size_t)b * 32 + i]; s1 += o1[(size_t)b * 32 + i]; }
+        worst = fmax(worst, fabs(s0 - s1) / fabs(s0));
+    }
+    printf("worst relative difference of block sums: %.3e\n", worst);
+    return 0;
+}
