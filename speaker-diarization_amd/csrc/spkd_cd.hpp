@@ -32,6 +32,7 @@ struct TurnDesc {
     int64_t cand_cap;    // candidate slots owned by this turn
     int64_t ev_off;      // first event slot
     int64_t ev_cap;      // event slots owned by this turn
+    int64_t id;          // caller's turn index (blocks are launched longest turn first)
 };
 
 // e in [0, QUSE) -> quad-record index and the (row, column) it holds
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(GW_TPB) void k_gw(
     __shared__ double s_ldS;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
-    const int turn = blockIdx.x;
-    const TurnDesc T = turns[turn];
+    const TurnDesc T = turns[blockIdx.x];
+    const int turn = (int)T.id;
     const long long n = T.len;
     const float* fr = frames + T.begin * D;
     double* snap = snap_all + T.snap_off * QREC;

@@ -17,6 +17,7 @@
 #pragma once
 #include "spkd_device.hpp"
 #include "spkd_quad.hpp"
+#include "spkd_blocked.hpp"
 #include "../../include/spkd.h"
 
 namespace spkd {
@@ -218,73 +219,87 @@ __device__ __forceinline__ void single_pair_matrix(int kind, const double* __res
     }
 }
 
-// Quad evaluation of the log det a distance needs for FOUR partner records at
-// once: the lane's DPP row handles partner qrC (or the cluster itself when self).
-// BIC: log det of the covariance of the union; GLR: of (nA S_A + nC S_C) / N.
+// Column source for the blocked elimination: the matrix whose log det a pair
+// distance needs, for FOUR partner records at once (DPP row m: partner qrC, or the
+// cluster itself when self).  BIC: covariance of the union; GLR: (nA S_A + nC S_C)/N.
+//   column j = wa * A[:, j] + wc * C[:, j] + k1 v1 v1_j + k2 v2 v2_j
+// with the covariance scale folded into wa, wc, k1 (BIC: v1 = sums of the union,
+// k1 = -f / n, k2 = 0;  GLR: v1 = sums of A, v2 = sums of C).
+struct PairSrc {
+    const double* ldsA;      // LDS quad record of A
+    const double* gC;        // global quad record of the partner, + lane offset
+    int ta;                  // opaque lane offset for the LDS reads
+    double wa, wc;
+    double v1[QS], v2[QS];   // rank-one vectors (sums columns)
+    double k1, k2;           // their coefficients: column j += k1 v1 v1_j + k2 v2 v2_j
+
+    template <int J>
+    __device__ __forceinline__ void load(double (&col)[QS]) {
+#pragma unroll
+        for (int s = 0; s < QS; ++s) col[s] = gC[(s * DA + J) * 16];
+    }
+    template <int J>
+    __device__ __forceinline__ void finish(double (&col)[QS]) {
+        const double v1j = bcast16<J % QL>(v1[J / QL]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s)
+            col[s] = fma(k1 * v1[s], v1j, fma(wa, ldsA[(s * DA + J) * 16 + ta], wc * col[s]));
+        // second rank-one term (GLR); c2 = 0 otherwise.  Kept unconditional: a branch
+        // per column (39 small divergent regions) wrecks the register allocation
+        const double v2j = bcast16<J % QL>(v2[J / QL]);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) col[s] = fma(k2 * v2[s], v2j, col[s]);
+    }
+};
+
 // ldsA: quad record of cluster A staged in LDS (all four matrices share it);
-// gA: the same record in global memory (fallback path only).
+// gA: the same record in global memory (fallback path only); schur: per-wave LDS tile.
 __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA, double nA,
                                                    const double* __restrict__ gA,
                                                    const double* __restrict__ qrC, bool self,
                                                    const QuadLane& L, const double* const* qrC_by_m,
-                                                   const bool* self_by_m, int* err) {
-    QuadRows q;
-    double sv[QS], svc[QS];
+                                                   const bool* self_by_m, double* schur, int* err) {
+    PairSrc src;
     const double nC = self ? 0.0 : qr_count(qrC);
     const double n = nA + nC;
-    // q = wa * A + wc * C with the covariance scale 1 / (n - 1) folded into the weights
     const bool glr = (kind == SPKD_GLR && !self);
     const double f = 1.0 / (n - 1.0);
-    double wa = f, wc = self ? 0.0 : f;
+    src.wa = f;
+    src.wc = self ? 0.0 : f;
     if (glr) {
-        wa = (nA / n) / (nA - 1.0);
-        wc = (nC / n) / (nC - 1.0);
+        src.wa = (nA / n) / (nA - 1.0);
+        src.wc = (nC / n) / (nC - 1.0);
     }
-    // phase 1: the partner's rows straight into the row registers (120 loads in
-    // flight, no extra registers); phase 2: slot by slot, q = wa * A + wc * C with
-    // A read from LDS.  The scheduling barriers keep the LDS reads of a slot from
-    // being hoisted above the previous slot (that would need 234 more VGPRs).
-#pragma unroll
-    for (int s = 0; s < QS; ++s) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) q.r[s][j] = qrC[(s * DA + j) * 16 + L.t];
-        svc[s] = qrC[(s * DA + D) * 16 + L.t];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // A is the same for every partner of the caller's loop: an opaque lane offset keeps
-    // its 120 LDS reads inside the loop instead of pinned in 234 VGPRs across it
+    src.ldsA = ldsA;
+    src.gC = qrC + L.t;
     int ta = L.t;
-    asm volatile("" : "+v"(ta));
+    asm volatile("" : "+v"(ta));          // keeps A's LDS reads inside the caller's loop
+    src.ta = ta;
+    src.k1 = glr ? -(src.wa / nA) : -(f / n);
+    src.k2 = glr ? -(src.wc / nC) : 0.0;
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) q.r[s][j] = fma(wa, ldsA[(s * DA + j) * 16 + ta], wc * q.r[s][j]);
-        sv[s] = ldsA[(s * DA + D) * 16 + ta];
-        __builtin_amdgcn_sched_barrier(0);
+        const double sa = ldsA[(s * DA + D) * 16 + ta];
+        const double sc = self ? 0.0 : qrC[(s * DA + D) * 16 + L.t];
+        src.v1[s] = glr ? sa : sa + sc;
+        src.v2[s] = glr ? sc : 0.0;
     }
-    if (glr) {
-        double c1[QS], c2[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            c1[s] = -((wa / nA) * sv[s]);
-            c2[s] = -((wc / nC) * svc[s]);
+    bool ok;
+    double ld = quad_logdet_blocked(src, schur, L, ok);
+    // matrices that met a pivot that is not a positive finite number (this is also
+    // how NaN / inf entries surface) are redone one at a time with partial pivoting
+    const unsigned long long badmask = __ballot(!ok);
+    if (badmask) {
+#pragma unroll 1
+        for (int mi = 0; mi < 4; ++mi) {
+            if (((badmask >> (16 * mi)) & 0xffffull) == 0ull) continue;   // wave-uniform
+            double a[DA];
+            single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
+            const double v = logdet_pivoted_fn(a, err);
+            if (L.m == mi) ld = v;
         }
-        QuadRank1<0>::run(q, c1, sv);
-        QuadRank1<0>::run(q, c2, svc);
-    } else {
-        // S = f (Q - s s^T / n): the rank-one term with the scale folded in
-        double c1[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-            sv[s] += self ? 0.0 : svc[s];
-            c1[s] = -((f / n) * sv[s]);
-        }
-        QuadRank1<0>::run(q, c1, sv);
     }
-    auto form_single = [&](int mi, double (&a)[DA]) {
-        single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
-    };
-    return quad_logdet(q, L.m, err, form_single);
+    return ld;
 }
 
 __device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
@@ -360,7 +375,7 @@ __device__ __forceinline__ int find_problem(const int64_t* __restrict__ seg_off,
     return (int)lo;
 }
 
-constexpr int MX_WAVES = 4;
+constexpr int MX_WAVES = 8;
 
 // grid.x = total number of records; block g computes row a = g - seg_off[p] of
 // problem p: D[a][c] for c > a (and D[c][a] for variant 1), plus the diagonal /
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
     __shared__ double ldsA[QREC];
+    __shared__ double schur[MX_WAVES * SCHUR_TILE];
     const int64_t g = blockIdx.x;
     const int p = find_problem(seg_off, n_prob, g);
     const int64_t off = seg_off[p];
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
             const bool valid = rc < N;
             rc = valid ? rc : N - 1;
             const double* C = ex + (off + rc) * QREC;
-            const double ldx = quad_pair_logdet(kind, ldsA, nA, A, C, false, L, recs, selfs, err);
+            const double ldx = quad_pair_logdet(kind, ldsA, nA, A, C, false, L, recs, selfs, schur + wave * SCHUR_TILE, err);
             const double d = finish_distance(kind, lambdac, nA, ldA, qr_count(C), ld[off + rc], ldx);
             if (valid && L.t == 0) {
                 Dm[ra * N + rc] = d;
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
 }
 
 // ---------------------------------------------------------------------------
-constexpr int AHC_WAVES = 4;
+constexpr int AHC_WAVES = 8;
 constexpr int AHC_TPB = AHC_WAVES * WAVE;
 
 struct ArgMin {
@@ -472,6 +488,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         double* __restrict__ final_max, double* __restrict__ final_min, int* err) {
     extern __shared__ int32_t ids[];                    // alive partner slots of the merged cluster
     __shared__ double ldsA[QREC];
+    __shared__ double schur[AHC_WAVES * SCHUR_TILE];
     __shared__ ArgMin red[AHC_WAVES];
     __shared__ ArgMin best;
     __shared__ int s_cnt[2];
@@ -621,7 +638,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
                 const int32_t slot = ids[k];
-                const double v = quad_pair_logdet(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
+                const double v = quad_pair_logdet(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, schur + wave * SCHUR_TILE, err);
                 if (valid && L.t == 0) {
                     if (k == 0) ldp[sa] = v; else tp[slot] = v;
                 }

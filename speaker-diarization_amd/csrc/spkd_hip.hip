@@ -478,8 +478,12 @@ spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const 
         n_cand += T.cand_cap;
         T.ev_off = h_off[t];
         T.ev_cap = h_off[t + 1] - h_off[t];
+        T.id = t;
         if (T.ev_cap < 0) return fail(c, SPKD_EINVAL, "offsets must be non-decreasing");
     }
+    // longest turns first: a turn is a serial chain on one workgroup, so this is the
+    // classic LPT order that keeps the tail of the launch short
+    if (gw) std::stable_sort(turns.begin(), turns.end(), [](const TurnDesc& a, const TurnDesc& b) { return a.len > b.len; });
     return SPKD_OK;
 }
 }  // namespace
