@@ -110,3 +110,74 @@ def test_cli_case_matches_reference(case, tmp_path, eng):
         # 1e-5 relative applies; BIC / GLR are held to 1e-9.
         kl2 = 'KL2' in case['argv_tail']
         assert_stdout_close(stdout, case['stdout'], rel=1e-5 if kl2 else 1e-9)
+
+
+def _same_merges(a, b):
+    assert len(a) == len(b), (a, b)
+    for (a1, b1, d1), (a2, b2, d2) in zip(a, b):
+        assert (a1, b1) == (a2, b2), (a, b)
+        if math.isnan(d2):
+            assert math.isnan(d1)
+        elif math.isinf(d2):
+            assert d1 == d2
+        else:
+            assert abs(d1 - d2) <= 1e-9 * max(1.0, abs(d2))
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+def test_ahc_nan_and_inf_semantics_follow_numpy(eng, variant):
+    """Digital-silence segments: a zero covariance gives log det = -inf, two of
+    them give a NaN distance; numpy's min() then returns NaN and the merge loop
+    stops at once unless -ms forces it, in which case argmin is the first NaN
+    (SURVEY.md A-5, A-7).  Compared with the literal numpy restatement."""
+    from oracle.numpy_engine import NumpyEngine
+    synth = pkg('synth')
+    feats, _, truth = synth.make_session(77, 120, 3)
+    f = feats.copy()
+    segs = [(a, b) for a, b, _ in truth][:9]
+    f[segs[2][0]:segs[2][1]] = 0.0           # two all-zero segments
+    f[segs[6][0]:segs[6][1]] = 0.0
+    ne = NumpyEngine()
+    ne.set_features(f)
+    eng.set_features(f)
+    for max_spk in (0, 4):
+        want = ne.cluster_hi(segs, variant, 'BIC', 1.3, 0.0, max_spk)
+        got = eng.cluster_hi(segs, variant, 'BIC', 1.3, 0.0, max_spk)
+        _same_merges(got.merges, want.merges)
+    # one zero segment only: +inf distances, never merged, the rest clusters normally
+    f2 = feats.copy()
+    f2[segs[2][0]:segs[2][1]] = 0.0
+    ne.set_features(f2)
+    eng.set_features(f2)
+    want = ne.cluster_hi(segs, variant, 'BIC', 1.3, 0.0, 0)
+    got = eng.cluster_hi(segs, variant, 'BIC', 1.3, 0.0, 0)
+    _same_merges(got.merges, want.merges)
+    assert len(got.merges) >= 1
+
+
+def test_sliding_window_and_merge_modes_on_a_longer_file(eng, tmp_path):
+    """sw (GLR), m (BIC with the frozen c1, GLR) on 10 minutes against the C oracle."""
+    import io
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    cli = pkg('cli')
+    feats, vad, _ = synth.make_session(606, 600, 4)
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'ten.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as fh:
+        fh.write(synth.vad_recipe_text('ten.wav', vad))
+    outs = {}
+    for tag, e in (('hip', eng), ('orc', COracleEngine())):
+        sw = os.path.join(tmp, tag + '.sw.recipe')
+        cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), os.path.join(tmp, 'fea'), '-o', sw,
+                                   '-t', '3000'], engine=e, stdout=io.StringIO())
+        res = [open(sw).read()]
+        for dist, extra in (('BIC', ['-l', '1.3']), ('GLR', ['-t', '1500'])):
+            m = os.path.join(tmp, tag + '.m.' + dist + '.recipe')
+            cli.main_change_detection([sw, os.path.join(tmp, 'fea'), '-o', m, '-m', 'm', '-d', dist] + extra,
+                                      engine=e, stdout=io.StringIO())
+            res.append(open(m).read())
+        outs[tag] = res
+    assert outs['hip'] == outs['orc']
+    assert outs['hip'][0].count('\n') > len(vad)

@@ -1,0 +1,135 @@
+"""CPU tests of the host-side logic (recipe grammar, Python-2 number formatting, lna
+renaming, feature files) and property tests of the sufficient-statistics algebra
+the kernels rely on."""
+import io
+import math
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from conftest import pkg
+
+recipe = pkg('recipe')
+feaio = pkg('feaio')
+synth = pkg('synth')
+
+
+def test_py2_float_str_matches_python2_semantics():
+    f = recipe.py2_float_str
+    assert f(1.0) == '1.0'
+    assert f(13.492) == '13.492'
+    assert f(1561.5 / 125 + 1.0) == '13.492'          # 12 significant digits hide the last ulps
+    assert f(0.1 + 0.2) == '0.3'
+    assert f(123456789012.5) in ('123456789012.0', '123456789013.0')   # round-half-even of the 12th digit
+    assert f(1e16) == '1e+16'
+    assert f(1e-5) == '1e-05'
+    assert f(float('inf')) == 'inf' and f(float('-inf')) == '-inf' and f(float('nan')) == 'nan'
+    assert f(100000000000.0) == '100000000000.0'
+    assert f(1000000000000.0) == '1e+12'
+
+
+@given(st.floats(min_value=0.0, max_value=1e6, allow_nan=False))
+@settings(max_examples=300, deadline=None)
+def test_roundtrip_is_idempotent(x):
+    once = float(recipe.py2_float_str(x))
+    assert float(recipe.py2_float_str(once)) == once
+    assert abs(once - x) <= 5e-12 * max(1.0, abs(x))
+
+
+def test_parse_recipe_skips_and_echoes_bad_lines():
+    text = ['audio=a.wav lna=a_1 start-time=1.0 end-time=2.5\n',
+            'audio=a.wav lna=a_2 start-time=3 end-time=4.0\n',        # integer-only time: no match
+            'lna=a_3 start-time=5.0 end-time=6.0\n',                   # no audio
+            'audio=b.wav lna=b_1 start-time=1e+3 end-time=2000.0 speaker=x\n',   # exponent form: no match
+            'audio=c.wav alignment=x lna=c_9 start-time=10.25 end-time=11.5 speaker=spk_turn\n']
+    echoed = []
+    r = recipe.parse_recipe(text, echo=echoed.append)
+    assert [tuple(x) for x in r] == [('a.wav', 'a_1', 1.0, 2.5), ('c.wav', 'c_9', 10.25, 11.5)]
+    assert echoed.count('Recipe line without recognizable data:') == 3
+
+
+def test_lna_renaming_state_machine():
+    out = io.StringIO()
+    w = recipe.RecipeWriter(out, 125.0)
+    rl = lambda lna: recipe.RecipeLine('x.wav', lna, 0.0, 1.0)
+    for lna in ('a_1', 'a_1', 'a_7', 'b_2', 'b_2', 'a_3', 'noscore'):
+        w.write(rl(lna), 0, 125, 0, 'spk_turn')
+    names = [ln.split()[1] for ln in out.getvalue().splitlines()]
+    # counter continues inside a prefix, restarts on a new one; without '_' the prefix is
+    # everything but the last character and the name becomes the counter alone (A-10)
+    assert names == ['lna=a_1', 'lna=a_2', 'lna=a_3', 'lna=b_1', 'lna=b_2', 'lna=a_1', 'lna=1']
+    out2 = io.StringIO()
+    w2 = recipe.RecipeWriter(out2, 125.0, rename_lna=False)
+    w2.write(rl('zz_9'), 250, 375, 1.5, 'speaker_3')
+    assert out2.getvalue() == 'audio=x.wav lna=zz_9 start-time=3.5 end-time=4.5 speaker=speaker_3\n'
+
+
+def test_fea_roundtrip_and_errors(tmp_path):
+    feats = np.arange(5 * 39, dtype=np.float32).reshape(5, 39)
+    p = os.path.join(str(tmp_path), 'a.fea')
+    synth.write_fea(p, feats)
+    dim, back = feaio.load_features(p)
+    assert dim == 39 and np.array_equal(back, feats)
+    with open(p, 'ab') as f:
+        f.write(b'\x00\x00\x00\x00')                    # a dangling partial frame
+    with pytest.raises(ValueError):
+        feaio.load_features(p)
+    assert feaio.fea_path('/x/y/meeting.wav', 'fea', '.fea') == os.path.join('fea', 'meeting.fea')
+    assert feaio.fea_path('/x/y/meeting.wav', 'fea/', '.fea', join=False) == 'fea/meeting.fea'
+
+
+def test_synthetic_generator_is_reproducible():
+    a, va, ta = synth.make_session(11, 40, 3)
+    b, vb, tb = synth.make_session(11, 40, 3)
+    assert synth.fea_sha256(a) == synth.fea_sha256(b) and va == vb and ta == tb
+    c, _, _ = synth.make_session(12, 40, 3)
+    assert synth.fea_sha256(a) != synth.fea_sha256(c)
+    assert a.dtype == np.float32 and a.shape == (5000, 39)
+    covered = sum(e - s for s, e in va)
+    assert 0 < covered < a.shape[0]
+
+
+# ---------------------------------------------------------------- statistics algebra
+def _rec(x):
+    xa = np.concatenate([x.astype(np.float64), np.ones((x.shape[0], 1))], axis=1)
+    m = xa.T @ xa
+    return np.concatenate([m[r, r:] for r in range(40)])
+
+
+def _cov_from_rec(rec):
+    m = np.zeros((40, 40))
+    k = 0
+    for r in range(40):
+        m[r, r:] = rec[k:k + 40 - r]
+        k += 40 - r
+    m = m + np.triu(m, 1).T
+    n = m[39, 39]
+    s = m[:39, 39]
+    return (m[:39, :39] - np.outer(s, s) / n) / (n - 1)
+
+
+@given(st.integers(min_value=0, max_value=2 ** 31), st.integers(min_value=45, max_value=400),
+       st.integers(min_value=45, max_value=400))
+@settings(max_examples=25, deadline=None)
+def test_merged_statistics_give_numpy_cov_of_the_concatenation(seed, n1, n2):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((n1, 39)) * rng.uniform(0.5, 2.0, 39) + rng.standard_normal(39)).astype(np.float32)
+    y = (rng.standard_normal((n2, 39)) * rng.uniform(0.5, 2.0, 39) + rng.standard_normal(39)).astype(np.float32)
+    got = _cov_from_rec(_rec(x) + _rec(y))
+    want = np.cov(np.concatenate((x, y)), rowvar=0)
+    assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want))
+    # permutation invariance of the record
+    perm = rng.permutation(n1)
+    assert np.allclose(_rec(x[perm]), _rec(x), rtol=1e-13, atol=1e-9)
+
+
+def test_c_oracle_statistics_match_the_algebra():
+    from oracle.c_engine import COracleEngine
+    feats, _, _ = synth.make_session(3, 30, 2)
+    e = COracleEngine()
+    e.set_features(feats)
+    got = e.stats([[(10, 500)], [(0, 100), (200, 260)]])
+    assert np.allclose(got[0], _rec(feats[10:500]), rtol=1e-13, atol=1e-9)
+    assert np.allclose(got[1], _rec(np.concatenate((feats[0:100], feats[200:260]))), rtol=1e-13, atol=1e-9)
