@@ -343,7 +343,16 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
         k2a = 0.0; k2b = 0.0; k2c = 0.0; w2 = 0.0;
         al *= f; be *= f; ga *= f;          // covariance scale folded into the combine
     }
-    quad_prefix_rows(q, svb, snap, fr, b, nturn, L, edge);
+    if (pass != PASS_POOLED) {
+        quad_prefix_rows(q, svb, snap, fr, b, nturn, L, edge);
+    } else {                              // al = 0: R(b) is not part of the pooled window
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) q.r[s][j] = 0.0;
+            svb[s] = 0.0;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
