@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spkd.h"
@@ -592,12 +593,80 @@ spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
 }
 
 // ------------------------------------------------------------------ (5) host helpers
-void spkd_py2_roundtrip(double* v, int64_t n) {
+// float('%.12g' % x) without printf for the common range: x = m 2^k exactly, so
+// x 10^s (s = 11 - floor(log10 x)) is formed exactly in 128-bit integers, rounded half
+// to even to a 12-digit integer q, and q / 10^s (both exact doubles) is one correctly
+// rounded IEEE division -- the same value a correctly rounded strtod gives.
+static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+static const uint64_t kPow10u[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull,
+                                     10000000ull, 100000000ull, 1000000000ull, 10000000000ull,
+                                     100000000000ull, 1000000000000ull, 10000000000000ull,
+                                     100000000000000ull, 1000000000000000ull, 10000000000000000ull,
+                                     100000000000000000ull, 1000000000000000000ull,
+                                     10000000000000000000ull};
+
+static bool roundtrip_fast(double x, double* out) {
+    if (!(x >= 1e-3 && x < 1e11)) return false;
+    int e10 = (int)std::floor(std::log10(x));
+    if (e10 < -3) e10 = -3;
+    if (e10 >= 0) { if (x < kPow10[e10]) --e10; else if (e10 + 1 <= 22 && x >= kPow10[e10 + 1]) ++e10; }
+    else { if (x * kPow10[-e10] < 1.0) --e10; else if (x * kPow10[-e10 - 1] >= 1.0) ++e10; }
+    if (e10 < -3 || e10 > 10) return false;
+    int s = 11 - e10;                              // 1 .. 14
+    int k;
+    const double fr = std::frexp(x, &k);            // x = fr 2^k, 0.5 <= fr < 1
+    const uint64_t m = (uint64_t)std::ldexp(fr, 53);   // 53-bit integer mantissa
+    k -= 53;                                        // x = m 2^k
+    unsigned __int128 prod = (unsigned __int128)m * kPow10u[s];
+    uint64_t q;
+    if (k >= 0) {
+        if (k > 20) return false;
+        q = (uint64_t)(prod << k);
+    } else {
+        const int sh = -k;
+        if (sh >= 120) return false;
+        const unsigned __int128 one = 1;
+        const unsigned __int128 fl = prod >> sh;
+        const unsigned __int128 remn = prod & ((one << sh) - 1);
+        const unsigned __int128 half = one << (sh - 1);
+        q = (uint64_t)fl;
+        if (remn > half || (remn == half && (q & 1))) ++q;
+    }
+    if (q >= 1000000000000ull) {                    // rounded up to 13 digits: one digit less
+        // 10^12 exactly: value is 10^(e10+1)
+        if (q != 1000000000000ull) return false;
+        q = 100000000000ull;
+        s -= 1;
+    } else if (q < 100000000000ull) {
+        return false;                               // exponent estimate off: let printf decide
+    }
+    *out = s >= 0 ? (double)q / kPow10[s] : (double)q * kPow10[-s];
+    return true;
+}
+
+static void roundtrip_range(double* v, int64_t lo, int64_t hi) {
     char buf[64];
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = lo; i < hi; ++i) {
+        double r;
+        if (roundtrip_fast(v[i], &r)) { v[i] = r; continue; }
         std::snprintf(buf, sizeof buf, "%.12g", v[i]);
         v[i] = std::strtod(buf, nullptr);
     }
+}
+
+void spkd_py2_roundtrip(double* v, int64_t n) {
+    // correctly rounded printf / strtod, split over a few host threads for big batches
+    const int64_t kMinPerThread = 8192;
+    int nthreads = (int)std::min<int64_t>(8, n / kMinPerThread);
+    if (nthreads <= 1) { roundtrip_range(v, 0, n); return; }
+    std::vector<std::thread> pool;
+    const int64_t step = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t lo = t * step, hi = std::min<int64_t>(n, lo + step);
+        if (lo < hi) pool.emplace_back(roundtrip_range, v, lo, hi);
+    }
+    for (auto& th : pool) th.join();
 }
 
 spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t* h_a, const int32_t* h_b,

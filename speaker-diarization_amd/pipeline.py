@@ -11,6 +11,8 @@ segments are absolute frame ranges into it.  One k_gw launch covers every turn o
 every file, one k_chunk_stats/k_reduce_sets pair every segment, one
 k_cluster_prep/k_matrix/k_ahc triple every file (a clustering problem each).
 """
+import time
+
 import numpy as np
 
 from . import hipabi
@@ -34,6 +36,7 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     """Returns, per file, the list of (start_s, end_s) the change-detection recipe
     would contain (already passed through the 12-digit text round trip)."""
     rate = float(rate)
+    _t0 = time.perf_counter()
     nturn = [len(f.vad) for f in files]
     if sum(nturn) == 0:
         return [[] for _ in files]
@@ -48,7 +51,9 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     p = hipabi.CdParams(hipabi.KINDS[cd['kind']], 0, cd['lambdac'], cd['threshold'],
                         float(np.floor(cd['winsize_s'] * rate)), float(np.floor(cd['winstep_s'] * rate)),
                         float(np.floor(rate * cd['deltaws_s'])), rate)
+    _t1 = time.perf_counter()
     r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096, tight=True)
+    _t2 = time.perf_counter()
     if timings is not None:
         timings.setdefault('gw', []).append(ctx.last_ms('gw'))
         timings['gw_frames'] = int((te - tb).sum())
@@ -81,7 +86,13 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     rt = hipabi.py2_roundtrip(np.stack([t0, t1], axis=1).ravel()).reshape(-1, 2)
     line_file = owner[line_turn]
     bounds = np.searchsorted(line_file, np.arange(len(files) + 1))
-    return [rt[bounds[i]:bounds[i + 1]] for i in range(len(files))]
+    out = [rt[bounds[i]:bounds[i + 1]] for i in range(len(files))]
+    if timings is not None:
+        _t3 = time.perf_counter()
+        timings.setdefault('wall_cd_prepare', []).append(1e3 * (_t1 - _t0))
+        timings.setdefault('wall_cd_call', []).append(1e3 * (_t2 - _t1))
+        timings.setdefault('wall_cd_finish', []).append(1e3 * (_t3 - _t2))
+    return out
 
 
 def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=DIA2_CL, timings=None,
@@ -90,6 +101,7 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
     them.  Returns per file (labels[int array, 1-based, per segment in input
     order], merges[(a, b, d)])."""
     rate = float(rate)
+    _t0 = time.perf_counter()
     cnt = [len(s) for s in segments]
     seg_off = np.zeros(len(files) + 1, dtype=np.int64)
     seg_off[1:] = np.cumsum(cnt)
@@ -102,8 +114,10 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
     a1 = np.maximum(a0, np.clip((allseg[:, 1] * rate).astype(np.int64), 0, fn))
     b, e = foff + a0, foff + a1
     d_stats = ctx.dev_alloc(max(n, 1) * hipabi.REC * 8)
+    _t1 = time.perf_counter()
     try:
         ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
+        _t2 = time.perf_counter()
         if timings is not None:
             timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
             timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
@@ -112,6 +126,7 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
         p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], 0,
                              cl['lambdac'], cl['threshold'])
         r = ctx.ahc(d_stats, seg_off, p)
+        _t3 = time.perf_counter()
         if timings is not None:
             for k in ('cluster_prep', 'matrix', 'ahc'):
                 timings.setdefault(k, []).append(ctx.last_ms(k))
@@ -131,6 +146,12 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
         a, bb, d = r['a'][o:o + nm], r['b'][o:o + nm], r['d'][o:o + nm]
         labels = hipabi.labels_from_merges(c, a, bb)
         out.append((labels, list(zip(a.tolist(), bb.tolist(), d.tolist())) if want_merges else None))
+    if timings is not None:
+        _t4 = time.perf_counter()
+        timings.setdefault('wall_cl_prepare', []).append(1e3 * (_t1 - _t0))
+        timings.setdefault('wall_cl_stats_call', []).append(1e3 * (_t2 - _t1))
+        timings.setdefault('wall_cl_ahc_call', []).append(1e3 * (_t3 - _t2))
+        timings.setdefault('wall_cl_finish', []).append(1e3 * (_t4 - _t3))
     return out
 
 

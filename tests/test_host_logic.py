@@ -133,3 +133,40 @@ def test_c_oracle_statistics_match_the_algebra():
     got = e.stats([[(10, 500)], [(0, 100), (200, 260)]])
     assert np.allclose(got[0], _rec(feats[10:500]), rtol=1e-13, atol=1e-9)
     assert np.allclose(got[1], _rec(np.concatenate((feats[0:100], feats[200:260]))), rtol=1e-13, atol=1e-9)
+
+
+def test_library_roundtrip_helper_equals_python_formatting():
+    """spkd_py2_roundtrip (exact 128-bit fast path + printf fallback) against the
+    pure-Python '%.12g' round trip, bit for bit."""
+    hipabi = pkg('hipabi')
+    rng = np.random.default_rng(2026)
+    groups = [rng.random(50000) * 10.0 ** rng.integers(-3, 11, 50000),
+              rng.integers(0, 4500000, 50000) / 125.0 + rng.integers(0, 3000, 50000) / 1000.0,
+              np.arange(20000) * 0.0005 + 0.00025,                      # decimal ties after scaling
+              np.array([0.0, 1e-3, 99999999999.5, 9.9999999999995, 1.0000000000005, 13.492,
+                        1561.5 / 125 + 1.0, 1e11, 5e-4, 1e15, 2.5e-3, 123456789.0125])]
+    for v in groups:
+        got = hipabi.py2_roundtrip(v)
+        want = np.array([float(recipe.py2_float_str(x)) for x in v])
+        assert np.array_equal(got, want)
+
+
+def test_labels_from_merges_helper():
+    hipabi = pkg('hipabi')
+    import random
+    random.seed(5)
+    n = 40
+    clusters = [[i] for i in range(n)]
+    a_list, b_list = [], []
+    for _ in range(31):
+        m = len(clusters)
+        a = random.randrange(m - 1)
+        b = random.randrange(a + 1, m)
+        a_list.append(a); b_list.append(b)
+        clusters[a].extend(clusters[b])
+        clusters.pop(b)
+    want = [0] * n
+    for k, c in enumerate(clusters):
+        for i in c:
+            want[i] = k + 1
+    assert hipabi.labels_from_merges(n, a_list, b_list).tolist() == want
