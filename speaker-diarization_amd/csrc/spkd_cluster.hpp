@@ -225,6 +225,7 @@ __device__ __forceinline__ void single_pair_matrix(int kind, const double* __res
 //   column j = wa * A[:, j] + wc * C[:, j] + k1 v1 v1_j + k2 v2 v2_j
 // with the covariance scale folded into wa, wc, k1 (BIC: v1 = sums of the union,
 // k1 = -f / n, k2 = 0;  GLR: v1 = sums of A, v2 = sums of C).
+template <bool TWO>
 struct PairSrc {
     const double* ldsA;      // LDS quad record of A
     const double* gC;        // global quad record of the partner, + lane offset
@@ -244,25 +245,28 @@ struct PairSrc {
 #pragma unroll
         for (int s = 0; s < QS; ++s)
             col[s] = fma(k1 * v1[s], v1j, fma(wa, ldsA[(s * DA + J) * 16 + ta], wc * col[s]));
-        // second rank-one term (GLR); c2 = 0 otherwise.  Kept unconditional: a branch
-        // per column (39 small divergent regions) wrecks the register allocation
-        const double v2j = bcast16<J % QL>(v2[J / QL]);
+        // second rank-one term (GLR only).  A compile-time switch: a run-time branch per
+        // column (39 small divergent regions) wrecks the register allocation
+        if constexpr (TWO) {
+            const double v2j = bcast16<J % QL>(v2[J / QL]);
 #pragma unroll
-        for (int s = 0; s < QS; ++s) col[s] = fma(k2 * v2[s], v2j, col[s]);
+            for (int s = 0; s < QS; ++s) col[s] = fma(k2 * v2[s], v2j, col[s]);
+        }
     }
 };
 
 // ldsA: quad record of cluster A staged in LDS (all four matrices share it);
 // gA: the same record in global memory (fallback path only); schur: per-wave LDS tile.
+template <bool TWO>
 __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA, double nA,
                                                    const double* __restrict__ gA,
                                                    const double* __restrict__ qrC, bool self,
                                                    const QuadLane& L, const double* const* qrC_by_m,
                                                    const bool* self_by_m, double* schur, int* err) {
-    PairSrc src;
+    PairSrc<TWO> src;
     const double nC = self ? 0.0 : qr_count(qrC);
     const double n = nA + nC;
-    const bool glr = (kind == SPKD_GLR && !self);
+    const bool glr = TWO && (kind == SPKD_GLR && !self);
     const double f = 1.0 / (n - 1.0);
     src.wa = f;
     src.wc = self ? 0.0 : f;
@@ -380,6 +384,7 @@ constexpr int MX_WAVES = 8;
 // grid.x = total number of records; block g computes row a = g - seg_off[p] of
 // problem p: D[a][c] for c > a (and D[c][a] for variant 1), plus the diagonal /
 // lower-triangle initial values.  Each wave evaluates four partners per pass.
+template <bool TWO>
 __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
         const double* __restrict__ ex, const int64_t* __restrict__ seg_off, int64_t n_prob,
         int variant, int kind, double lambdac,
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
             const bool valid = rc < N;
             rc = valid ? rc : N - 1;
             const double* C = ex + (off + rc) * QREC;
-            const double ldx = quad_pair_logdet(kind, ldsA, nA, A, C, false, L, recs, selfs, schur + wave * SCHUR_TILE, err);
+            const double ldx = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, false, L, recs, selfs, schur + wave * SCHUR_TILE, err);
             const double d = finish_distance(kind, lambdac, nA, ldA, qr_count(C), ld[off + rc], ldx);
             if (valid && L.t == 0) {
                 Dm[ra * N + rc] = d;
@@ -476,6 +481,7 @@ __device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
 // of an O(N^2) scan, with numpy's first-occurrence / NaN semantics intact.
 constexpr int NO_COL = 0x7fffffff;
 
+template <bool TWO>
 __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         double* __restrict__ ex, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double lambdac, double threshold,
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
                 const int32_t slot = ids[k];
-                const double v = quad_pair_logdet(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, schur + wave * SCHUR_TILE, err);
+                const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, schur + wave * SCHUR_TILE, err);
                 if (valid && L.t == 0) {
                     if (k == 0) ldp[sa] = v; else tp[slot] = v;
                 }

@@ -341,8 +341,9 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
         TIMED(c, SPKD_T_CLUSTER_PREP,
               hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
                                  (const double*)B.ex, n_total, kind, B.ld, B.aux, c->d_err));
+        auto kmat = kind == SPKD_GLR ? k_matrix<true> : k_matrix<false>;   // GLR has a second rank-one term
         TIMED(c, SPKD_T_MATRIX,
-              hipLaunchKernelGGL(k_matrix, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
+              hipLaunchKernelGGL(kmat, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
                                  (const double*)B.ex, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
                                  (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
                                  B.smax, B.smin, c->d_err));
@@ -415,10 +416,11 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     int32_t* d_n = d_rcache + 3 * n_total;
     const size_t lds = (size_t)(n_max + 4) * sizeof(int32_t);
     if (lds > 150 * 1024) return fail(c, SPKD_EINVAL, "clustering problem too large for one workgroup's LDS");
+    auto kahc = P->kind == SPKD_GLR ? k_ahc<true> : k_ahc<false>;
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_ahc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)kahc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TIMED(c, SPKD_T_AHC,
-          hipLaunchKernelGGL(k_ahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
+          hipLaunchKernelGGL(kahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
                              B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                              P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
                              d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));

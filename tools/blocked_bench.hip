@@ -11,7 +11,7 @@
 using namespace spkd;
 
 // BIC union covariance of (A in LDS, C in global), column by column
-struct PairSrc {
+struct BenchSrc {
     const double* ldsA;     // LDS quad record of A
     const double* gC;       // global quad record of C (already + lane t)
     int t;
@@ -50,11 +50,25 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void k_pairs(const double* _
         int rc = base + L.m; rc = rc < n_rec ? rc : n_rec - 1;
         const double* C = qr + (size_t)rc * QREC;
         if (MODE == 0) {
-            const double* recs[4]; bool selfs[4];
-            for (int mi = 0; mi < 4; ++mi) { int c = base + mi; c = c < n_rec ? c : n_rec - 1; recs[mi] = qr + (size_t)c * QREC; selfs[mi] = false; }
-            acc += quad_pair_logdet(SPKD_BIC, ldsA, nA, A, C, false, L, recs, selfs, err);
+            // unblocked: whole matrix in registers (one wave per SIMD)
+            QuadRows q; double sv[QS], svc[QS];
+            int ta = L.t; asm volatile("" : "+v"(ta));
+            const double n = nA + C[QREC_COUNT_AT];
+            const double f = 1.0 / (n - 1.0);
+            quad_load_scaled(C + L.t, 0, f, q, svc);
+            __builtin_amdgcn_sched_barrier(0);
+            double c1[QS];
+            for (int s2 = 0; s2 < QS; ++s2) {
+                for (int j = 0; j < D; ++j) q.r[s2][j] = fma(f, ldsA[(s2 * DA + j) * 16 + ta], q.r[s2][j]);
+                sv[s2] = ldsA[(s2 * DA + D) * 16 + ta] + svc[s2];
+                c1[s2] = -((f / n) * sv[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            QuadRank1<0>::run(q, c1, sv);
+            double det; quad_det_nopivot(q, det);
+            acc += log(det);
         } else {
-            PairSrc src;
+            BenchSrc src;
             int ta = L.t; asm volatile("" : "+v"(ta));
             src.ldsA = ldsA; src.gC = C + L.t; src.t = ta;
             const double n = nA + C[QREC_COUNT_AT];
