@@ -189,11 +189,17 @@ spkd_status spkd_sw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
  *   finite distance evaluated (NaN when never updated from the reference's
  *   initial 0 / maxint); variant 2 = max / min of the final matrix.
  */
+/* Launch shape of the merge loop.  MONO: one workgroup per problem, the whole loop in
+ * one launch (many files per call).  WIDE: every merge round is a pair of launches
+ * whose log-det work spreads over all CUs (one long file).  AUTO picks by problem
+ * count.  Results are identical. */
+enum { SPKD_AHC_AUTO = 0, SPKD_AHC_MONO = 1, SPKD_AHC_WIDE = 2 };
+
 typedef struct {
     int32_t variant;     /* 1 or 2 */
     int32_t kind;        /* spkd_kind */
     int32_t max_spk;     /* -ms */
-    int32_t reserved;
+    int32_t path;        /* SPKD_AHC_AUTO / _MONO / _WIDE */
     double lambdac;
     double threshold;
 } spkd_ahc_params;

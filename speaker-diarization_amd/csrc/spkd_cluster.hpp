@@ -480,6 +480,70 @@ __device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
 // two merged clusters, so an iteration costs O(N) plus a few row rescans instead
 // of an O(N^2) scan, with numpy's first-occurrence / NaN semantics intact.
 constexpr int NO_COL = 0x7fffffff;
+constexpr int AHC_MAX_N = 65536;       // records per problem (row-flag masks live in LDS)
+
+// Row-cache refresh: every alive row flagged dirty gets its minimum, the first
+// column holding it and its first NaN column recomputed.  The flags are read 64
+// rows per load and the dirty ones taken from the ballot, so a round with few
+// dirty rows costs a few memory latencies, not one per row.
+__device__ __forceinline__ void refresh_rows(const double* __restrict__ Dm, long long N,
+                                             const int32_t* __restrict__ al, int32_t* __restrict__ dirty,
+                                             double* __restrict__ rmin, int32_t* __restrict__ rarg,
+                                             int32_t* __restrict__ rnan, unsigned long long* masks,
+                                             int tid, int wave, int lane) {
+    // phase A: snapshot of the flags, one 64-row mask per LDS word
+    const long long n_chunks = (N + WAVE - 1) / WAVE;
+    for (long long ch = wave; ch < n_chunks; ch += AHC_WAVES) {
+        const long long rl = ch * WAVE + lane;
+        const long long rc = rl < N ? rl : N - 1;
+        const int fa = al[rc], fd = dirty[rc];
+        const unsigned long long mk = __ballot(rl < N && fa && fd);
+        if (lane == 0) masks[ch] = mk;
+    }
+    __syncthreads();
+    // phase B: wave w takes every 8th dirty row (the snapshot makes the count the
+    // same in every wave although rows are being marked clean meanwhile)
+    int ord = 0;
+    for (long long ch = 0; ch < n_chunks; ++ch) {
+        const long long r0 = ch * WAVE;
+        unsigned long long todo = masks[ch];
+        while (todo) {
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            if ((ord++ & (AHC_WAVES - 1)) != wave) continue;
+            const long long r = r0 + b;
+            const double* row = Dm + r * N;
+            double mv = __builtin_huge_val();
+            int mc = NO_COL, nc = NO_COL;
+            for (long long c0 = 0; c0 < N; c0 += 4 * WAVE) {
+                double v[4];
+                int a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long c = c0 + u * WAVE + lane;
+                    const long long cc = c < N ? c : N - 1;
+                    a[u] = (c < N) ? al[cc] : 0;
+                    v[u] = row[cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = (int)(c0 + u * WAVE + lane);
+                    if (!a[u]) continue;
+                    if (v[u] != v[u]) { if (c < nc) nc = c; continue; }
+                    if (v[u] < mv || (v[u] == mv && c < mc)) { mv = v[u]; mc = c; }
+                }
+            }
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const double v2 = __shfl_xor(mv, s);
+                const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+                if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+                nc = n2 < nc ? n2 : nc;
+            }
+            if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; dirty[r] = 0; }
+        }
+    }
+}
 
 template <bool TWO>
 __global__ __launch_bounds__(AHC_TPB) void k_ahc(
@@ -496,6 +560,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     __shared__ double ldsA[QREC];
     __shared__ double schur[AHC_WAVES * SCHUR_TILE];
     __shared__ ArgMin red[AHC_WAVES];
+    __shared__ unsigned long long s_masks[AHC_MAX_N / WAVE];
     __shared__ ArgMin best;
     __shared__ int s_cnt[2];
     __shared__ int s_nids;
@@ -521,26 +586,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     double fmin = 0.0;
     while (true) {
         // ---- 0. refresh the cache of the rows a merge invalidated (wave per row)
-        for (long long r = wave; r < N; r += AHC_WAVES) {
-            if (!al[r] || !dirty[r]) continue;
-            const double* row = Dm + r * N;
-            double mv = __builtin_huge_val();
-            int mc = NO_COL, nc = NO_COL;
-            for (long long c = lane; c < N; c += WAVE) {
-                if (!al[c]) continue;
-                const double v = row[c];
-                if (v != v) { if ((int)c < nc) nc = (int)c; continue; }
-                if (v < mv || (v == mv && (int)c < mc)) { mv = v; mc = (int)c; }
-            }
-#pragma unroll
-            for (int s = 1; s < WAVE; s <<= 1) {
-                const double v2 = __shfl_xor(mv, s);
-                const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
-                if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
-                nc = n2 < nc ? n2 : nc;
-            }
-            if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; dirty[r] = 0; }
-        }
+        refresh_rows(Dm, N, al, dirty, rmin, rarg, rnan, s_masks, tid, wave, lane);
         __syncthreads();
         // ---- 1. min / argmin over the alive sub-matrix, numpy semantics: first
         // occurrence in row-major order; any NaN -> min is NaN and argmin the first
@@ -677,7 +723,11 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             const int ra = rarg[c], rn = rnan[c];
             if (variant == 1) {
                 Dm[c * N + sa] = d;
-                if (ra == sa || ra == sb || rn == sa || rn == sb) dirty[c] = 1;
+                if (ra == sa || ra == sb || rn == sa || rn == sb) {
+                    // a strictly smaller value at sa is the new row minimum whatever the rest holds
+                    if (rn != sa && rn != sb && d < rmin[c]) { rmin[c] = d; rarg[c] = (int)sa; }
+                    else dirty[c] = 1;
+                }
                 else if (d != d) { if ((int)sa < rn) rnan[c] = (int)sa; }
                 else if (d < rmin[c] || (d == rmin[c] && (int)sa < ra)) { rmin[c] = d; rarg[c] = (int)sa; }
                 if (stat_valid(d)) {
@@ -732,6 +782,392 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         out_n[p] = n_merges;
         final_max[p] = mx;
         final_min[p] = fmin;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// The same merge loop split over kernel launches ("wide" form): when there are
+// few problems (one long file, BASELINE.json configs 2 / 5) one workgroup per
+// problem leaves the chip idle and the loop is a serial chain of N - 1 rounds.
+// Here every round is three launches:
+//   k_ahc_update (a wave per row, all CUs)  finish the previous round's distances,
+//                write row / column sa, bring every row cache up to date (rows
+//                whose cached minimum was invalidated are rescanned on the spot);
+//   k_ahc_select (one workgroup per problem)  arg-min over the row caches, the
+//                stop decision, merge of the two records, partner list;
+//   k_ahc_pairs  (ceil(partners / 32) workgroups per problem)  the log dets.
+// The host enqueues N rounds back to back without reading anything: a problem
+// that stopped sets state.done and its later launches return at once.  No
+// inter-workgroup waiting anywhere, so no co-residency requirement.
+// Arithmetic, tie-breaks and NaN rules are those of k_ahc.
+struct AhcState {
+    int32_t done, n_merges, nids, pad;
+    long long sa, sb;
+    double nA, fmin;
+};
+
+// distance of the merged cluster sa to cluster c from the finished log dets
+// (k_ahc step 4; KL2 from the auxiliary records, 39 terms in index order)
+__device__ __forceinline__ double ahc_finish(int kind, double lambdac, const double* __restrict__ ex,
+                                             const double* __restrict__ aux, const double* __restrict__ ldp,
+                                             const double* __restrict__ tp, int64_t off, long long sa,
+                                             long long c, double nA, double ldA) {
+    if (kind == SPKD_KL2) {
+        const double* a1 = aux + (off + sa) * AUX;
+        const double* a2 = aux + (off + c) * AUX;
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < D; ++i) {
+            const float dm = (float)a1[2 * DA + i] - (float)a2[2 * DA + i];
+            const double delta = (double)dm;
+            t1 += (a1[i] - a2[i]) * (a2[DA + i] - a1[DA + i]);
+            t2 += ((a1[DA + i] + a2[DA + i]) * delta) * delta;
+        }
+        return 0.5 * t1 + 0.5 * t2;
+    }
+    const double nC = qr_count(ex + (off + c) * QREC);
+    return finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
+}
+
+// wave-wide (min, first column, first NaN column) of one row; sub_col >= 0
+// replaces that column's stored value by sub_val (the caller's own fresh write)
+__device__ __forceinline__ void ahc_scan_row(const double* __restrict__ row, long long N,
+                                             const int32_t* __restrict__ al, bool all_alive,
+                                             long long sub_col, double sub_val, int lane,
+                                             double& mv, int& mc, int& nc) {
+    mv = __builtin_huge_val();
+    mc = NO_COL; nc = NO_COL;
+    for (long long c0 = 0; c0 < N; c0 += 4 * WAVE) {
+        double v[4];
+        int a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long c = c0 + u * WAVE + lane;
+            const long long cc = c < N ? c : N - 1;
+            a[u] = (c < N) ? (all_alive ? 1 : al[cc]) : 0;
+            v[u] = row[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long cl = c0 + u * WAVE + lane;
+            const int c = (int)cl;
+            if (!a[u]) continue;
+            const double x = (cl == sub_col) ? sub_val : v[u];
+            if (x != x) { if (c < nc) nc = c; continue; }
+            if (x < mv || (x == mv && c < mc)) { mv = x; mc = c; }
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double v2 = __shfl_xor(mv, s);
+        const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+        if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+        nc = n2 < nc ? n2 : nc;
+    }
+}
+
+// grid (ceil(n_max / 8), n_prob); wave w of block x owns row 8 x + w
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_update(
+        int it, const double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        int variant, int kind, double lambdac,
+        const double* __restrict__ ld, const double* __restrict__ aux,
+        double* __restrict__ mat, const int64_t* __restrict__ mat_off,
+        int32_t* __restrict__ alive, const double* __restrict__ tmp,
+        double* __restrict__ rmin_all, int32_t* __restrict__ rcache_all,
+        const AhcState* __restrict__ state) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int p = blockIdx.y;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    const long long r = (long long)blockIdx.x * AHC_WAVES + wave;
+    if (r >= N) return;
+    double* Dm = mat + mat_off[p];
+    int32_t* al = alive + off;
+    const double* ldp = ld + off;
+    const double* tp = tmp + off;
+    double* rmin = rmin_all + off;
+    int32_t* rarg = rcache_all + 3 * off;
+    int32_t* rnan = rarg + N;
+    double mv;
+    int mc, nc;
+    if (it == 0) {                    // first round: every row from the full matrix
+        ahc_scan_row(Dm + r * N, N, al, true, -1, 0.0, lane, mv, mc, nc);
+        if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; al[r] = 1; }
+        return;
+    }
+    const AhcState* S = state + p;
+    if (S->done || !al[r]) return;
+    const long long sa = S->sa, sb = S->sb;
+    const double nA = S->nA;
+    const double ldA = ldp[sa];
+    if (r == sa) return;             // row sa itself is rescanned by k_ahc_select
+    const double d = ahc_finish(kind, lambdac, ex, aux, ldp, tp, off, sa, r, nA, ldA);
+    const int ra = rarg[r], rn = rnan[r];
+    const double rm = rmin[r];
+    if (lane == 0) Dm[sa * N + r] = d;
+    if (variant == 1) {
+        if (lane == 0) Dm[r * N + sa] = d;
+        const bool nan_hit = (rn == sa || rn == sb);
+        if (ra == sa || ra == sb || nan_hit) {
+            if (!nan_hit && d < rm) {            // still (or now) the strict row minimum
+                if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
+            } else {
+                ahc_scan_row(Dm + r * N, N, al, false, sa, d, lane, mv, mc, nc);
+                if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
+            }
+        } else if (d != d) {
+            if (lane == 0 && (int)sa < rn) rnan[r] = (int)sa;
+        } else if (d < rm || (d == rm && (int)sa < ra)) {
+            if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
+        }
+    } else if (ra == sb || rn == sb) {           // column sa keeps its stale value (A-9)
+        ahc_scan_row(Dm + r * N, N, al, false, -1, 0.0, lane, mv, mc, nc);
+        if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
+    }
+}
+
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_select(
+        int it, double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        int variant, int kind, int max_spk, double threshold, double* __restrict__ aux,
+        const double* __restrict__ mat, const int64_t* __restrict__ mat_off,
+        int32_t* __restrict__ alive, double* __restrict__ rmin_all,
+        int32_t* __restrict__ rcache_all, int32_t* __restrict__ ids_all,
+        AhcState* __restrict__ state, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
+        double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
+        int* err) {
+    struct RowRed { double mv, wmax, wmin; int mc, nc; };
+    __shared__ RowRed rred[AHC_WAVES];
+    __shared__ ArgMin red[AHC_WAVES];
+    __shared__ ArgMin best;
+    __shared__ int s_cnt[2];
+    __shared__ int s_nids;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int p = blockIdx.x;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    int32_t* al = alive + off;
+    double* rmin = rmin_all + off;
+    int32_t* rarg = rcache_all + 3 * off;
+    int32_t* rnan = rarg + N;
+    int32_t* ids = ids_all + off;
+    AhcState* S = state + p;
+    const long long INF_IDX = 0x7fffffffffffffffLL;
+    int n_merges = 0;
+    if (it > 0) {
+        if (S->done) return;
+        n_merges = S->n_merges;
+        // ---- 0. the merged cluster's own row (k_ahc_update wrote it): cache + the
+        // running statistics of variant 1 over the distances just evaluated
+        const long long psa = S->sa;
+        const double* row = mat + mat_off[p] + psa * N;
+        double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
+        int mc = NO_COL, nc = NO_COL;
+#pragma unroll 4
+        for (long long c = tid; c < N; c += AHC_TPB) {
+            const int a = al[c];
+            const double d = row[c];
+            if (!a) continue;
+            if (variant == 1 && c != psa && stat_valid(d)) {
+                wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                wmin = (wmin != wmin || d < wmin) ? d : wmin;
+            }
+            if (d != d) { if ((int)c < nc) nc = (int)c; continue; }
+            if (d < mv || (d == mv && (int)c < mc)) { mv = d; mc = (int)c; }
+        }
+#pragma unroll
+        for (int s = 1; s < WAVE; s <<= 1) {
+            const double v2 = __shfl_xor(mv, s);
+            const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+            if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+            nc = n2 < nc ? n2 : nc;
+            const double x = __shfl_xor(wmax, s), y = __shfl_xor(wmin, s);
+            if (x == x && (wmax != wmax || x > wmax)) wmax = x;
+            if (y == y && (wmin != wmin || y < wmin)) wmin = y;
+        }
+        if (lane == 0) { rred[wave].mv = mv; rred[wave].mc = mc; rred[wave].nc = nc; rred[wave].wmax = wmax; rred[wave].wmin = wmin; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < AHC_WAVES; ++w) {
+                const RowRed o = rred[w];
+                if (o.mv < mv || (o.mv == mv && o.mc < mc)) { mv = o.mv; mc = o.mc; }
+                nc = o.nc < nc ? o.nc : nc;
+                if (o.wmax == o.wmax && (wmax != wmax || o.wmax > wmax)) wmax = o.wmax;
+                if (o.wmin == o.wmin && (wmin != wmin || o.wmin < wmin)) wmin = o.wmin;
+            }
+            rmin[psa] = mv; rarg[psa] = mc; rnan[psa] = nc;
+            if (variant == 1) {
+                if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
+                if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
+            }
+        }
+        __syncthreads();
+    }
+    const long long m = N - n_merges;
+    // ---- 1. arg-min over the row caches (k_ahc step 1)
+    ArgMin mine;
+    mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+#pragma unroll 4
+    for (long long r = tid; r < N; r += AHC_TPB) {
+        const int a = al[r];
+        const double v = rmin[r];
+        const int c = rarg[r], nc = rnan[r];
+        if (!a) continue;
+        if (nc != NO_COL) { const long long l = r * N + nc; if (l < mine.nan_idx) mine.nan_idx = l; }
+        if (c != NO_COL) {
+            const long long l = r * N + c;
+            if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        ArgMin o;
+        o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
+        argmin_merge(mine, o);
+    }
+    if (lane == 0) red[wave] = mine;
+    if (tid < 2) s_cnt[tid] = 0;
+    if (tid == 0) s_nids = 1;
+    __syncthreads();
+    if (tid == 0) {
+        ArgMin b = red[0];
+        for (int w = 1; w < AHC_WAVES; ++w) argmin_merge(b, red[w]);
+        best = b;
+    }
+    __syncthreads();
+    const bool has_nan = best.nan_idx != INF_IDX;
+    const double mind = has_nan ? __builtin_nan("") : best.v;
+    const long long index = has_nan ? best.nan_idx : best.idx;
+    const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
+    const long long r0 = index / N, c0 = index - r0 * N;
+    if (!go || r0 == c0) {
+        if (tid == 0) {
+            if (go) atomicOr(err, ERR_DEGENERATE_MERGE);
+            S->done = 1;
+            S->n_merges = n_merges;
+            S->fmin = mind;
+        }
+        return;
+    }
+    const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
+    // compacted indices = alive slots in front; partner list (any order)
+    {
+        int ca = 0, cb = 0;
+        for (long long c = tid; c < N; c += AHC_TPB) {
+            if (!al[c]) continue;
+            if (c < sb) { cb++; if (c < sa) ca++; }
+            if (c != sa && c != sb) ids[atomicAdd(&s_nids, 1)] = (int32_t)c;
+        }
+        if (ca) atomicAdd(&s_cnt[0], ca);
+        if (cb) atomicAdd(&s_cnt[1], cb);
+    }
+    // ---- 2. merge the statistics
+    double* A = ex + (off + sa) * QREC;
+    const double* B = ex + (off + sb) * QREC;
+    for (int e = tid; e < QREC; e += AHC_TPB) A[e] = A[e] + B[e];
+    __syncthreads();
+    const double nA = A[QREC_COUNT_AT];
+    if (kind == SPKD_KL2 && wave == 0) {
+        double a[DA];
+        single_rows_from_qr(A, a);
+        const double mean_i = a[D] / nA;
+        cov_rows(a, nA);
+        kl2_aux_from_cov(a, mean_i, aux + (off + sa) * AUX);
+    }
+    if (tid == 0) {
+        const int64_t o = off + n_merges;
+        out_a[o] = s_cnt[0]; out_b[o] = s_cnt[1]; out_d[o] = mind;
+        al[sb] = 0;
+        ids[0] = (int32_t)sa;
+        S->done = 0;
+        S->sa = sa; S->sb = sb; S->nA = nA; S->nids = s_nids;
+        S->n_merges = n_merges + 1;
+        S->fmin = mind;
+    }
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_pairs(
+        const double* __restrict__ ex, const int64_t* __restrict__ seg_off, int kind,
+        double* __restrict__ ld, double* __restrict__ tmp, const int32_t* __restrict__ ids_all,
+        const AhcState* __restrict__ state, int* err) {
+    __shared__ double ldsA[QREC];
+    __shared__ double schur[AHC_WAVES * SCHUR_TILE];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const QuadLane L = quad_lane();
+    const int p = blockIdx.y;
+    const AhcState* S = state + p;
+    if (S->done) return;
+    const int nids = S->nids;
+    if ((int)blockIdx.x * 4 * AHC_WAVES >= nids) return;
+    const int64_t off = seg_off[p];
+    const int32_t* ids = ids_all + off;
+    const long long sa = S->sa;
+    const double* A = ex + (off + sa) * QREC;
+    for (int e = tid; e < QREC; e += AHC_TPB) ldsA[e] = A[e];
+    __syncthreads();
+    const double nA = ldsA[QREC_COUNT_AT];
+    const int base = ((int)blockIdx.x * AHC_WAVES + wave) * 4;
+    if (base >= nids) return;
+    const double* recs[4];
+    bool selfs[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        int k = base + mi;
+        k = k < nids ? k : nids - 1;
+        recs[mi] = ex + (off + ids[k]) * QREC;
+        selfs[mi] = (k == 0);
+    }
+    int k = base + L.m;
+    const bool valid = k < nids;
+    k = valid ? k : nids - 1;
+    const int32_t slot = ids[k];
+    const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs,
+                                           schur + wave * SCHUR_TILE, err);
+    if (valid && L.t == 0) {
+        if (k == 0) ld[off + sa] = v; else tmp[off + slot] = v;
+    }
+}
+
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_final(
+        const int64_t* __restrict__ seg_off, const double* __restrict__ mat,
+        const int64_t* __restrict__ mat_off, const int32_t* __restrict__ alive,
+        const AhcState* __restrict__ state, int32_t* __restrict__ out_n,
+        double* __restrict__ final_max, double* __restrict__ final_min) {
+    __shared__ double s_tmax[AHC_WAVES];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int p = blockIdx.x;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    const double* Dm = mat + mat_off[p];
+    const int32_t* al = alive + off;
+    double tmax = -__builtin_huge_val();
+    bool anynan = false;
+    for (long long r = wave; r < N; r += AHC_WAVES) {
+        if (!al[r]) continue;
+        const double* row = Dm + r * N;
+        for (long long c = lane; c < N; c += WAVE) {
+            if (!al[c]) continue;
+            const double v = row[c];
+            if (v != v) anynan = true; else tmax = v > tmax ? v : tmax;
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double t2 = __shfl_xor(tmax, s);
+        tmax = t2 > tmax ? t2 : tmax;
+    }
+    anynan = __any(anynan);
+    if (lane == 0) s_tmax[wave] = anynan ? __builtin_nan("") : tmax;
+    __syncthreads();
+    if (tid == 0) {
+        double mx = s_tmax[0];
+        for (int w = 1; w < AHC_WAVES; ++w) {
+            const double x = s_tmax[w];
+            if (mx == mx) mx = (x != x) ? x : (x > mx ? x : mx);
+        }
+        out_n[p] = state[p].n_merges;
+        final_max[p] = mx;
+        final_min[p] = state[p].fmin;
     }
 }
 

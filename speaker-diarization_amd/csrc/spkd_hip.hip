@@ -399,31 +399,68 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     if ((st = ahc_prepare(c, d_stats, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs)) != SPKD_OK) return st;
     int64_t n_max = 0;
     for (int64_t p = 0; p < n_prob; ++p) n_max = std::max<int64_t>(n_max, h_seg_off[p + 1] - h_seg_off[p]);
+    if (n_max > AHC_MAX_N) return fail(c, SPKD_EINVAL, "clustering problem larger than 65536 records");
     // outputs + per-slot scratch
     void* op = nullptr;
-    const size_t out_bytes = (size_t)n_total * (6 * sizeof(int32_t) + 3 * sizeof(double)) +
-                             (size_t)n_prob * (sizeof(int32_t) + 2 * sizeof(double)) + 64;
+    const size_t out_bytes = (size_t)n_total * (7 * sizeof(int32_t) + 3 * sizeof(double)) +
+                             (size_t)n_prob * (sizeof(int32_t) + 2 * sizeof(double) + sizeof(AhcState)) + 64;
     if ((st = scratch(c, S_AHC_OUT, out_bytes, &op)) != SPKD_OK) return st;
     double* d_merge_d = (double*)op;
     double* d_tmp = d_merge_d + n_total;
     double* d_rmin = d_tmp + n_total;
     double* d_fmax = d_rmin + n_total;
     double* d_fmin = d_fmax + n_prob;
-    int32_t* d_a = (int32_t*)(d_fmin + n_prob);
+    AhcState* d_state = (AhcState*)(d_fmin + n_prob);
+    int32_t* d_a = (int32_t*)(d_state + n_prob);
     int32_t* d_b = d_a + n_total;
     int32_t* d_alive = d_b + n_total;
     int32_t* d_rcache = d_alive + n_total;           // 3 ints per record: arg col, NaN col, dirty
-    int32_t* d_n = d_rcache + 3 * n_total;
+    int32_t* d_ids = d_rcache + 3 * n_total;         // wide form: partner list per problem
+    int32_t* d_n = d_ids + n_total;
+    // one workgroup per problem fills the chip only when there are many problems;
+    // with few, the merge loop runs as a chain of launches over all CUs instead
+    int path = P->path;
+    if (path != SPKD_AHC_MONO && path != SPKD_AHC_WIDE) path = n_prob <= 16 ? SPKD_AHC_WIDE : SPKD_AHC_MONO;
     const size_t lds = (size_t)(n_max + 4) * sizeof(int32_t);
-    if (lds > 150 * 1024) return fail(c, SPKD_EINVAL, "clustering problem too large for one workgroup's LDS");
-    auto kahc = P->kind == SPKD_GLR ? k_ahc<true> : k_ahc<false>;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)kahc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    TIMED(c, SPKD_T_AHC,
-          hipLaunchKernelGGL(kahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
-                             B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
-                             P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
-                             d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
+    if (path == SPKD_AHC_MONO && lds > 150 * 1024) path = SPKD_AHC_WIDE;
+    if (path == SPKD_AHC_MONO) {
+        auto kahc = P->kind == SPKD_GLR ? k_ahc<true> : k_ahc<false>;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)kahc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        TIMED(c, SPKD_T_AHC,
+              hipLaunchKernelGGL(kahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
+                                 B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
+                                 P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
+                                 d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
+    } else {
+        auto kpairs = P->kind == SPKD_GLR ? k_ahc_pairs<true> : k_ahc_pairs<false>;
+        (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
+        const unsigned row_blocks = (unsigned)((n_max + AHC_WAVES - 1) / AHC_WAVES);
+        for (int64_t it = 0; it < n_max; ++it) {
+            hipLaunchKernelGGL(k_ahc_update, dim3(row_blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                               (int)it, (const double*)B.ex, (const int64_t*)B.seg_off, P->variant, P->kind,
+                               P->lambdac, (const double*)B.ld, (const double*)B.aux, B.mat,
+                               (const int64_t*)B.mat_off, d_alive, (const double*)d_tmp, d_rmin, d_rcache,
+                               (const AhcState*)d_state);
+            hipLaunchKernelGGL(k_ahc_select, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                               (int)it, B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk,
+                               P->threshold, B.aux, (const double*)B.mat, (const int64_t*)B.mat_off, d_alive,
+                               d_rmin, d_rcache, d_ids, d_state, d_a, d_b, d_merge_d, B.smax, B.smin,
+                               c->d_err);
+            if (it + 1 < n_max && P->kind != SPKD_KL2) {
+                const int64_t partners = n_max - it - 1;       // alive clusters after merge `it`
+                const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + 4 * AHC_WAVES - 1) / (4 * AHC_WAVES));
+                hipLaunchKernelGGL(kpairs, dim3(blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                                   (const double*)B.ex, (const int64_t*)B.seg_off, P->kind, B.ld, d_tmp,
+                                   (const int32_t*)d_ids, (const AhcState*)d_state, c->d_err);
+            }
+        }
+        hipLaunchKernelGGL(k_ahc_final, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                           (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off,
+                           (const int32_t*)d_alive, (const AhcState*)d_state, d_n, d_fmax, d_fmin);
+        (void)hipEventRecord(c->kb[SPKD_T_AHC], c->stream);
+        c->kused[SPKD_T_AHC] = true;
+    }
     HIPCHK(c, hipGetLastError());
     std::vector<unsigned long long> kmax((size_t)n_prob), kmin((size_t)n_prob);
     std::vector<double> fmax((size_t)n_prob), fmin((size_t)n_prob);

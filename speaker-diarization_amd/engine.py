@@ -21,6 +21,7 @@ class HipEngine(object):
         self.n_frames = 0
         self._owned = []
         self.last_ms = {}
+        self.ahc_path = hipabi.AHC_AUTO     # AHC_MONO / AHC_WIDE force one launch shape
 
     # ------------------------------------------------------------- memory
     def close(self):
@@ -160,7 +161,7 @@ class HipEngine(object):
         d = self._stats_of_sets([[s] for s in segs])
         self.last_ms['stats'] = self.ctx.last_ms()
         try:
-            p = hipabi.AhcParams(variant, hipabi.KINDS[kind], max_spk, 0, lambdac, threshold)
+            p = hipabi.AhcParams(variant, hipabi.KINDS[kind], max_spk, self.ahc_path, lambdac, threshold)
             r = self.ctx.ahc(d, [0, len(segs)], p)
             self.last_ms['ahc'] = self.ctx.last_ms()
         finally:

@@ -36,9 +36,12 @@ class CandLog(C.Structure):
                 ('n1', C.c_int64), ('n2', C.c_int64)]
 
 
+AHC_AUTO, AHC_MONO, AHC_WIDE = 0, 1, 2
+
+
 class AhcParams(C.Structure):
     _fields_ = [('variant', C.c_int32), ('kind', C.c_int32), ('max_spk', C.c_int32),
-                ('reserved', C.c_int32), ('lambdac', C.c_double), ('threshold', C.c_double)]
+                ('path', C.c_int32), ('lambdac', C.c_double), ('threshold', C.c_double)]
 
 
 class SpkdError(RuntimeError):

@@ -123,7 +123,7 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
             timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
             timings['stats_frames'] = int((e - b).sum())
             timings['stats_sets'] = n
-        p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], 0,
+        p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], cl.get('path', 0),
                              cl['lambdac'], cl['threshold'])
         r = ctx.ahc(d_stats, seg_off, p)
         _t3 = time.perf_counter()

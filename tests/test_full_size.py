@@ -110,6 +110,43 @@ def test_distance_matrix_is_symmetric_and_matches_pair_terms(eng):
             k += 1
 
 
+@pytest.mark.parametrize('variant', [1, 2])
+def test_ahc_ragged_problems_wide_and_mono_agree(eng, variant):
+    """Several problems of different sizes in one spkd_ahc call (the largest ~1 700
+    segments: the statistics of a 4 h recording, BASELINE.json config 5 in small):
+    the chained-launch form (grids sized for the largest problem, smaller ones
+    finishing early) and the one-workgroup form give identical merge logs."""
+    synth = pkg('synth')
+    hipabi = pkg('hipabi')
+    feats, _, truth = synth.make_session(31337, 14400, 8)
+    eng.set_features(feats)
+    segs = [(a, b) for a, b, _ in truth]
+    sizes = [len(segs), 1, 37, 2, 300]
+    sets, seg_off = [], [0]
+    for k, n in enumerate(sizes):
+        sets += [[s] for s in segs[k:k + n]]
+        seg_off.append(seg_off[-1] + n)
+    d = eng._stats_of_sets(sets)
+    try:
+        res = {}
+        for path in (hipabi.AHC_MONO, hipabi.AHC_WIDE):
+            p = hipabi.AhcParams(variant, hipabi.KINDS['BIC'], 0, path, 1.3, 0.0)
+            res[path] = eng.ctx.ahc(d, seg_off, p)
+    finally:
+        eng.ctx.dev_free(d)
+    a, b = res[hipabi.AHC_MONO], res[hipabi.AHC_WIDE]
+    assert a['status'] == b['status'] == 0
+    assert np.array_equal(a['n_merges'], b['n_merges'])
+    assert a['n_merges'][0] > len(segs) - 40 and a['n_merges'][1] == 0
+    for k in range(len(sizes)):
+        lo, hi = seg_off[k], seg_off[k] + int(a['n_merges'][k])
+        assert np.array_equal(a['a'][lo:hi], b['a'][lo:hi])
+        assert np.array_equal(a['b'][lo:hi], b['b'][lo:hi])
+        assert np.array_equal(a['d'][lo:hi], b['d'][lo:hi])
+    assert np.array_equal(a['stat_max'], b['stat_max'], equal_nan=True)
+    assert np.array_equal(a['stat_min'], b['stat_min'], equal_nan=True)
+
+
 def test_batch_pipeline_equals_file_based_scripts(tmp_path, eng):
     """The in-memory batch pipeline (what bench.py times) must give, per file, the
     recipe rows the two drop-in scripts produce through files."""

@@ -112,7 +112,7 @@ def test_cli_case_matches_reference(case, tmp_path, eng):
         assert_stdout_close(stdout, case['stdout'], rel=1e-5 if kl2 else 1e-9)
 
 
-def _same_merges(a, b):
+def _same_merges(a, b, rel=1e-9):
     assert len(a) == len(b), (a, b)
     for (a1, b1, d1), (a2, b2, d2) in zip(a, b):
         assert (a1, b1) == (a2, b2), (a, b)
@@ -121,7 +121,7 @@ def _same_merges(a, b):
         elif math.isinf(d2):
             assert d1 == d2
         else:
-            assert abs(d1 - d2) <= 1e-9 * max(1.0, abs(d2))
+            assert abs(d1 - d2) <= rel * max(1.0, abs(d2))
 
 
 @pytest.mark.parametrize('variant', [1, 2])
@@ -153,6 +153,45 @@ def test_ahc_nan_and_inf_semantics_follow_numpy(eng, variant):
     got = eng.cluster_hi(segs, variant, 'BIC', 1.3, 0.0, 0)
     _same_merges(got.merges, want.merges)
     assert len(got.merges) >= 1
+
+
+@pytest.mark.parametrize('kind', ['BIC', 'GLR', 'KL2'])
+@pytest.mark.parametrize('variant', [1, 2])
+def test_ahc_launch_shapes_agree(eng, variant, kind):
+    """The merge loop has two launch shapes (one workgroup per problem / a chain of
+    launches over all CUs, spkd.h SPKD_AHC_*): same merges, same distances, same
+    summary statistics, both equal to the C oracle; with NaN / inf inputs too."""
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    hipabi = pkg('hipabi')
+    feats, _, truth = synth.make_session(4242, 600, 4)
+    segs = [(a, b) for a, b, _ in truth]
+    assert len(segs) > 40
+    thr = {'BIC': 0.0, 'GLR': 2500.0, 'KL2': 12.0}[kind]
+    orc = COracleEngine()
+    for zero in ((), (3, 11)):
+        f = feats.copy()
+        for z in zero:
+            f[segs[z][0]:segs[z][1]] = 0.0
+        orc.set_features(f)
+        eng.set_features(f)
+        for max_spk in (0, 3):
+            got = {}
+            for path in (hipabi.AHC_MONO, hipabi.AHC_WIDE):
+                eng.ahc_path = path
+                try:
+                    got[path] = eng.cluster_hi(segs, variant, kind, 1.3, thr, max_spk)
+                finally:
+                    eng.ahc_path = hipabi.AHC_AUTO
+            a, b = got[hipabi.AHC_MONO], got[hipabi.AHC_WIDE]
+            assert [(x, y) for x, y, _ in a.merges] == [(x, y) for x, y, _ in b.merges]
+            for (_, _, d1), (_, _, d2) in zip(a.merges, b.merges):
+                assert d1 == d2 or (math.isnan(d1) and math.isnan(d2))      # same arithmetic: bit-equal
+            for u, v in ((a.max_dist, b.max_dist), (a.min_dist, b.min_dist)):
+                assert u == v or (u is not None and v is not None and math.isnan(u) and math.isnan(v))
+            if kind != 'KL2' or not zero:
+                want = orc.cluster_hi(segs, variant, kind, 1.3, thr, max_spk)
+                _same_merges(b.merges, want.merges, rel=1e-5 if kind == 'KL2' else 1e-9)
 
 
 def test_sliding_window_and_merge_modes_on_a_longer_file(eng, tmp_path):
