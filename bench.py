@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--speakers', type=int, default=4)
     ap.add_argument('--cpu-sample-seconds', type=float, default=420.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ahc-path', type=int, default=0, help='0 auto, 1 one workgroup per file, 2 chained launches')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     ap.add_argument('--share-device', action='store_true',
                     help='rehearsal only: every rank uses GPU 0 (needs --backend gloo)')
@@ -126,7 +127,7 @@ def main():
     distributed = importlib.import_module(PKG + '.distributed')
 
     def step(tm=None):
-        rows = pipeline.diarize_batch(ctx, ptr, total, files, timings=tm)
+        rows = pipeline.diarize_batch(ctx, ptr, total, files, cl=dict(pipeline.DIA2_CL, path=args.ahc_path), timings=tm)
         if world == 1:
             return rows
         # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)

@@ -162,7 +162,7 @@ __device__ __forceinline__ void quad_prefix_rows(QuadRows& q, double (&sv)[QS],
 #pragma unroll
     for (int ss = 0; ss < QS; ++ss) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) q.r[ss][j] = s[(ss * DA + j) * 16 + L.t];
+        for (int j = 0; j < tri_cols(ss); ++j) q.r[ss][j] = s[(ss * DA + j) * 16 + L.t];
         sv[ss] = s[(ss * DA + D) * 16 + L.t];
     }
     int mx = ne;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void quad_prefix_rows(QuadRows& q, double (&sv)[QS],
             cx[ss] = sgn * x[ss];
             sv[ss] += cx[ss];
         }
-        QuadRank1<0>::run(q, cx, x);
+        TriRank1<0>::run(q, cx, x);
     }
 }
 
@@ -349,7 +349,7 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) q.r[s][j] = 0.0;
+            for (int j = 0; j < tri_cols(s); ++j) q.r[s][j] = 0.0;
             svb[s] = 0.0;
         }
     }
@@ -358,7 +358,7 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
+        for (int j = 0; j < tri_cols(s); ++j) {
             const double ra = ldsRa[(s * DA + j) * 16 + ta], rc = ldsRc[(s * DA + j) * 16 + ta];
             q.r[s][j] = fma(ga, rc, fma(be, ra, al * q.r[s][j]));
         }
@@ -369,13 +369,13 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
         c2[s] = w2 * v2[s];
         __builtin_amdgcn_sched_barrier(0);
     }
-    QuadRank1<0>::run(q, c1, v1);
-    if (pass == PASS_GLR) QuadRank1<0>::run(q, c2, v2);
+    TriRank1<0>::run(q, c1, v1);
+    if (pass == PASS_GLR) TriRank1<0>::run(q, c2, v2);
     auto form_single = [&](int mi, double (&arr)[DA]) {
         const long long bm = __shfl(b, 16 * mi);
         single_split_matrix(pass, ldsRa, ldsRc, snap, fr, a, bm, c, arr);
     };
-    return quad_logdet(q, L.m, err, form_single);
+    return tri_logdet(q, L.m, err, form_single);
 }
 
 constexpr int GW_WAVES = 4;
@@ -391,7 +391,7 @@ constexpr int GW_LDS_BYTES = 2 * QREC * 8 + (GW_EDGE_BYTES > GW_TILE_BYTES ? GW_
 // i = minfeas, minfeas + istep, ... (CD:204-221) and, after a positive one, a
 // fine scan over single-frame steps around the maximum (CD:235-251).  Both kinds
 // share one body, so the elimination code exists once.
-__global__ __launch_bounds__(GW_TPB) void k_gw(
+__global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ snap_all, double* __restrict__ cand_all,
         int32_t* __restrict__ n_win, double* __restrict__ win_maxd, int32_t* __restrict__ win_det,

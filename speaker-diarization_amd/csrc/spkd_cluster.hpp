@@ -17,7 +17,7 @@
 #pragma once
 #include "spkd_device.hpp"
 #include "spkd_quad.hpp"
-#include "spkd_blocked.hpp"
+#include "spkd_tri.hpp"
 #include "../../include/spkd.h"
 
 namespace spkd {
@@ -219,91 +219,65 @@ __device__ __forceinline__ void single_pair_matrix(int kind, const double* __res
     }
 }
 
-// Column source for the blocked elimination: the matrix whose log det a pair
-// distance needs, for FOUR partner records at once (DPP row m: partner qrC, or the
-// cluster itself when self).  BIC: covariance of the union; GLR: (nA S_A + nC S_C)/N.
-//   column j = wa * A[:, j] + wc * C[:, j] + k1 v1 v1_j + k2 v2 v2_j
+// log det of the matrix a pair distance needs, for FOUR partner records at once
+// (DPP row m: partner qrC, or the cluster itself when self).  BIC: covariance of
+// the union; GLR: (nA S_A + nC S_C) / N.  Lower triangle only (spkd_tri.hpp):
+//   entry (i, j) = wa * A_ij + wc * C_ij + k1 v1_i v1_j + k2 v2_i v2_j
 // with the covariance scale folded into wa, wc, k1 (BIC: v1 = sums of the union,
-// k1 = -f / n, k2 = 0;  GLR: v1 = sums of A, v2 = sums of C).
-template <bool TWO>
-struct PairSrc {
-    const double* ldsA;      // LDS quad record of A
-    const double* gC;        // global quad record of the partner, + lane offset
-    int ta;                  // opaque lane offset for the LDS reads
-    double wa, wc;
-    double v1[QS], v2[QS];   // rank-one vectors (sums columns)
-    double k1, k2;           // their coefficients: column j += k1 v1 v1_j + k2 v2 v2_j
-
-    template <int J>
-    __device__ __forceinline__ void load(double (&col)[QS]) {
-#pragma unroll
-        for (int s = 0; s < QS; ++s) col[s] = gC[(s * DA + J) * 16];
-    }
-    template <int J>
-    __device__ __forceinline__ void finish(double (&col)[QS]) {
-        const double v1j = bcast16<J % QL>(v1[J / QL]);
-#pragma unroll
-        for (int s = 0; s < QS; ++s)
-            col[s] = fma(k1 * v1[s], v1j, fma(wa, ldsA[(s * DA + J) * 16 + ta], wc * col[s]));
-        // second rank-one term (GLR only).  A compile-time switch: a run-time branch per
-        // column (39 small divergent regions) wrecks the register allocation
-        if constexpr (TWO) {
-            const double v2j = bcast16<J % QL>(v2[J / QL]);
-#pragma unroll
-            for (int s = 0; s < QS; ++s) col[s] = fma(k2 * v2[s], v2j, col[s]);
-        }
-    }
-};
-
+// k1 = -f / n, k2 = 0;  GLR: v1 = sums of A, v2 = sums of C).  The second rank-one
+// term is a compile-time switch (a run-time branch per column wrecks the register
+// allocation).
 // ldsA: quad record of cluster A staged in LDS (all four matrices share it);
-// gA: the same record in global memory (fallback path only); schur: per-wave LDS tile.
+// gA: the same record in global memory (fallback path only).
 template <bool TWO>
 __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA, double nA,
                                                    const double* __restrict__ gA,
                                                    const double* __restrict__ qrC, bool self,
                                                    const QuadLane& L, const double* const* qrC_by_m,
-                                                   const bool* self_by_m, double* schur, int* err) {
-    PairSrc<TWO> src;
+                                                   const bool* self_by_m, int* err) {
     const double nC = self ? 0.0 : qr_count(qrC);
     const double n = nA + nC;
     const bool glr = TWO && (kind == SPKD_GLR && !self);
     const double f = 1.0 / (n - 1.0);
-    src.wa = f;
-    src.wc = self ? 0.0 : f;
+    double wa = f, wc = self ? 0.0 : f;
     if (glr) {
-        src.wa = (nA / n) / (nA - 1.0);
-        src.wc = (nC / n) / (nC - 1.0);
+        wa = (nA / n) / (nA - 1.0);
+        wc = (nC / n) / (nC - 1.0);
     }
-    src.ldsA = ldsA;
-    src.gC = qrC + L.t;
+    const double k1 = glr ? -(wa / nA) : -(f / n);
+    const double k2 = glr ? -(wc / nC) : 0.0;
+    const double* Ct = qrC + L.t;
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keeps A's LDS reads inside the caller's loop
-    src.ta = ta;
-    src.k1 = glr ? -(src.wa / nA) : -(f / n);
-    src.k2 = glr ? -(src.wc / nC) : 0.0;
+    QuadRows q;
+    double sc[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {        // 81 loads in flight, one latency
+#pragma unroll
+        for (int j = 0; j < tri_cols(s); ++j) q.r[s][j] = Ct[(s * DA + j) * 16];
+        sc[s] = Ct[(s * DA + D) * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < tri_cols(s); ++j)
+            q.r[s][j] = fma(wa, ldsA[(s * DA + j) * 16 + ta], wc * q.r[s][j]);
         const double sa = ldsA[(s * DA + D) * 16 + ta];
-        const double sc = self ? 0.0 : qrC[(s * DA + D) * 16 + L.t];
-        src.v1[s] = glr ? sa : sa + sc;
-        src.v2[s] = glr ? sc : 0.0;
+        const double scs = self ? 0.0 : sc[s];
+        v1[s] = glr ? sa : sa + scs;
+        v2[s] = glr ? scs : 0.0;
+        c1[s] = k1 * v1[s];
+        c2[s] = k2 * v2[s];
+        __builtin_amdgcn_sched_barrier(0);
     }
-    bool ok;
-    double ld = quad_logdet_blocked(src, schur, L, ok);
-    // matrices that met a pivot that is not a positive finite number (this is also
-    // how NaN / inf entries surface) are redone one at a time with partial pivoting
-    const unsigned long long badmask = __ballot(!ok);
-    if (badmask) {
-#pragma unroll 1
-        for (int mi = 0; mi < 4; ++mi) {
-            if (((badmask >> (16 * mi)) & 0xffffull) == 0ull) continue;   // wave-uniform
-            double a[DA];
-            single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
-            const double v = logdet_pivoted_fn(a, err);
-            if (L.m == mi) ld = v;
-        }
-    }
-    return ld;
+    TriRank1<0>::run(q, c1, v1);
+    if constexpr (TWO) TriRank1<0>::run(q, c2, v2);
+    auto form_single = [&](int mi, double (&a)[DA]) {
+        single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
+    };
+    return tri_logdet(q, L.m, err, form_single);
 }
 
 __device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
@@ -353,9 +327,9 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
     double c1[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) c1[s] = -((fR / nR) * sv[s]);
-    QuadRank1<0>::run(q, c1, sv);
+    TriRank1<0>::run(q, c1, sv);
     auto form_single = [&](int mi, double (&a)[DA]) { single_pair_matrix(kind, recs[mi], recs[mi], true, a); };
-    const double v = quad_logdet(q, L.m, err, form_single);
+    const double v = tri_logdet(q, L.m, err, form_single);
     if (valid && L.t == 0) ld[c] = v;
 }
 
@@ -392,7 +366,6 @@ __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
     __shared__ double ldsA[QREC];
-    __shared__ double schur[MX_WAVES * SCHUR_TILE];
     const int64_t g = blockIdx.x;
     const int p = find_problem(seg_off, n_prob, g);
     const int64_t off = seg_off[p];
@@ -439,7 +412,7 @@ __global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
             const bool valid = rc < N;
             rc = valid ? rc : N - 1;
             const double* C = ex + (off + rc) * QREC;
-            const double ldx = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, false, L, recs, selfs, schur + wave * SCHUR_TILE, err);
+            const double ldx = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, false, L, recs, selfs, err);
             const double d = finish_distance(kind, lambdac, nA, ldA, qr_count(C), ld[off + rc], ldx);
             if (valid && L.t == 0) {
                 Dm[ra * N + rc] = d;
@@ -558,7 +531,6 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         double* __restrict__ final_max, double* __restrict__ final_min, int* err) {
     extern __shared__ int32_t ids[];                    // alive partner slots of the merged cluster
     __shared__ double ldsA[QREC];
-    __shared__ double schur[AHC_WAVES * SCHUR_TILE];
     __shared__ ArgMin red[AHC_WAVES];
     __shared__ unsigned long long s_masks[AHC_MAX_N / WAVE];
     __shared__ ArgMin best;
@@ -690,7 +662,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
                 const int32_t slot = ids[k];
-                const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, schur + wave * SCHUR_TILE, err);
+                const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
                 if (valid && L.t == 0) {
                     if (k == 0) ldp[sa] = v; else tp[slot] = v;
                 }
@@ -1091,7 +1063,6 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_pairs(
         double* __restrict__ ld, double* __restrict__ tmp, const int32_t* __restrict__ ids_all,
         const AhcState* __restrict__ state, int* err) {
     __shared__ double ldsA[QREC];
-    __shared__ double schur[AHC_WAVES * SCHUR_TILE];
     const int tid = threadIdx.x, wave = tid >> 6;
     const QuadLane L = quad_lane();
     const int p = blockIdx.y;
@@ -1121,8 +1092,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_pairs(
     const bool valid = k < nids;
     k = valid ? k : nids - 1;
     const int32_t slot = ids[k];
-    const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs,
-                                           schur + wave * SCHUR_TILE, err);
+    const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
     if (valid && L.t == 0) {
         if (k == 0) ld[off + sa] = v; else tmp[off + slot] = v;
     }

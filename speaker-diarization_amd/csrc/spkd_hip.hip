@@ -420,7 +420,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     // one workgroup per problem fills the chip only when there are many problems;
     // with few, the merge loop runs as a chain of launches over all CUs instead
     int path = P->path;
-    if (path != SPKD_AHC_MONO && path != SPKD_AHC_WIDE) path = n_prob <= 16 ? SPKD_AHC_WIDE : SPKD_AHC_MONO;
+    if (path != SPKD_AHC_MONO && path != SPKD_AHC_WIDE) path = n_prob <= 128 ? SPKD_AHC_WIDE : SPKD_AHC_MONO;
     const size_t lds = (size_t)(n_max + 4) * sizeof(int32_t);
     if (path == SPKD_AHC_MONO && lds > 150 * 1024) path = SPKD_AHC_WIDE;
     if (path == SPKD_AHC_MONO) {

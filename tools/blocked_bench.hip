@@ -8,6 +8,7 @@
 #include <vector>
 #include "spkd_cluster.hpp"
 #include "spkd_blocked.hpp"
+#include "spkd_tri.hpp"
 using namespace spkd;
 
 // BIC union covariance of (A in LDS, C in global), column by column
@@ -33,11 +34,14 @@ struct BenchSrc {
     }
 };
 
+#ifndef TRI_TPB
+#define TRI_TPB 512
+#endif
 template <int MODE>
-__global__ __launch_bounds__(MODE == 0 ? 256 : 512) void k_pairs(const double* __restrict__ qr, int n_rec,
+__global__ __launch_bounds__(MODE == 0 ? 256 : (MODE == 1 ? 512 : TRI_TPB)) void k_pairs(const double* __restrict__ qr, int n_rec,
                                                                    double* __restrict__ out, int* err) {
     __shared__ double ldsA[QREC];
-    __shared__ double schur[(MODE == 0 ? 1 : 8) * SCHUR_TILE];
+    __shared__ double schur[(MODE == 1 ? 8 : 1) * SCHUR_TILE];
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const QuadLane L = quad_lane();
     const int a = blockIdx.x % n_rec;
@@ -67,6 +71,32 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void k_pairs(const double* _
             QuadRank1<0>::run(q, c1, sv);
             double det; quad_det_nopivot(q, det);
             acc += log(det);
+        } else if (MODE == 2) {
+            // symmetric form: lower triangle only
+            QuadRows q; double sv[QS];
+            int ta = L.t; asm volatile("" : "+v"(ta));
+            const double n = nA + C[QREC_COUNT_AT];
+            const double f = 1.0 / (n - 1.0);
+            const double* Ct = C + L.t;
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) q.r[s2][j] = Ct[(s2 * DA + j) * 16];
+                sv[s2] = Ct[(s2 * DA + D) * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double c1[QS];
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) q.r[s2][j] = f * (ldsA[(s2 * DA + j) * 16 + ta] + q.r[s2][j]);
+                sv[s2] = ldsA[(s2 * DA + D) * 16 + ta] + sv[s2];
+                c1[s2] = -((f / n) * sv[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TriRank1<0>::run(q, c1, sv);
+            double det; tri_det_nopivot(q, det);
+            acc += log(det);
         } else {
             BenchSrc src;
             int ta = L.t; asm volatile("" : "+v"(ta));
@@ -79,7 +109,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 512) void k_pairs(const double* _
             acc += quad_logdet_blocked(src, schur + wave * SCHUR_TILE, L, ok);
         }
     }
-    if (L.t == 0) out[(size_t)blockIdx.x * 32 + wave * 4 + L.m] = acc;
+    if (L.t == 0) out[(size_t)blockIdx.x * 64 + wave * 4 + L.m] = acc;
 }
 
 int main(int argc, char** argv) {
@@ -101,27 +131,28 @@ int main(int argc, char** argv) {
         o[QREC_COUNT_AT] = nf;
     }
     double *dE, *dO0, *dO1; int* dErr;
-    hipMalloc(&dE, h.size() * 8); hipMalloc(&dO0, (size_t)blocks * 32 * 8); hipMalloc(&dO1, (size_t)blocks * 32 * 8); hipMalloc(&dErr, 4);
+    hipMalloc(&dE, h.size() * 8); hipMalloc(&dO0, (size_t)blocks * 64 * 8); hipMalloc(&dO1, (size_t)blocks * 64 * 8); hipMalloc(&dErr, 4);
     hipMemcpy(dE, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    hipMemset(dErr, 0, 4); hipMemset(dO0, 0, (size_t)blocks * 32 * 8); hipMemset(dO1, 0, (size_t)blocks * 32 * 8);
+    hipMemset(dErr, 0, 4); hipMemset(dO0, 0, (size_t)blocks * 64 * 8); hipMemset(dO1, 0, (size_t)blocks * 64 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode)
+    for (int mode = 0; mode < 3; ++mode)
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_pairs<0>, dim3(blocks), dim3(256), 0, 0, dE, n_rec, dO0, dErr);
-            else hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dO1, dErr);
+            else if (mode == 1) hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dO1, dErr);
+            else hipLaunchKernelGGL(k_pairs<2>, dim3(blocks), dim3(TRI_TPB), 0, 0, dE, n_rec, dO1, dErr);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            printf("%s: %.3f ms, %.1f M pairs/s\n", mode ? "blocked (8 waves)" : "quad    (4 waves)", ms, (double)blocks * n_rec / ms / 1e3);
+            printf("%s: %.3f ms, %.1f M pairs/s\n", mode == 0 ? "quad    (4 waves)" : mode == 1 ? "blocked (8 waves)" : "tri", ms, (double)blocks * n_rec / ms / 1e3);
         }
     // compare per-block sums: mode 0 has 16 slots per block, mode 1 has 32; compare block totals
-    std::vector<double> o0((size_t)blocks * 32), o1((size_t)blocks * 32);
+    std::vector<double> o0((size_t)blocks * 64), o1((size_t)blocks * 64);
     hipMemcpy(o0.data(), dO0, o0.size() * 8, hipMemcpyDeviceToHost);
     hipMemcpy(o1.data(), dO1, o1.size() * 8, hipMemcpyDeviceToHost);
     double worst = 0;
     for (int b = 0; b < blocks; ++b) {
         double s0 = 0, s1 = 0;
-        for (int i = 0; i < 32; ++i) { s0 += o0[(size_t)b * 32 + i]; s1 += o1[(size_t)b * 32 + i]; }
+        for (int i = 0; i < 64; ++i) { s0 += o0[(size_t)b * 64 + i]; s1 += o1[(size_t)b * 64 + i]; }
         worst = fmax(worst, fabs(s0 - s1) / fabs(s0));
     }
     printf("worst relative difference of block sums: %.3e\n", worst);
