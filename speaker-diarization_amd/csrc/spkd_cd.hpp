@@ -1,16 +1,21 @@
 // Change-detection kernels: growing window (dist_gw, spk-change-detection.py:180-288)
 // and sliding window (dist_sw, spk-change-detection.py:291-357, distances only).
 //
-// One workgroup per VAD turn.  Phase 1 turns the turn's frames into prefix
-// statistics snapshots every SNAP_G frames, stored as quad records (each frame is
-// read once, coalesced, staged through LDS, fp64 accumulation in frame order).
-// Phase 2 evaluates candidate split points: the statistics of any frame range
-// [x, y) are R(y) - R(x) with R(t) = snapshot[t / G] + the <= G-1 edge frames, so a
-// candidate costs one record read and one or two 39x39 eliminations instead of two
-// np.cov passes over raw frames.  Four candidates share a wave (quad layout,
-// spkd_quad.hpp).  The growing-window decision chain (a float state machine with
-// int() truncation) runs on the device with the exact operation
-// order of the reference.
+// Growing window: one workgroup per VAD turn.  The statistics of every frame range
+// the scan needs are differences of running moment sums P(t) = sum of [x;1][x;1]^T
+// over the frames [a, t) of the current epoch (a = the window start; a detection
+// starts a new epoch).  The workgroup sweeps each frame once per epoch, in frame
+// order, accumulating the lower triangle in registers (2x2 blocks, fp64), and
+// leaves a copy P(b) in a per-turn cache for every candidate split point b as the
+// sweep passes it, plus P(c) for the window end in LDS.  A candidate then costs one
+// 10 KB record read and one or two 39x39 symmetric eliminations -- no raw frames,
+// no edge corrections -- and is re-read, not re-formed, every time the window
+// grows.  Four candidates share a wave (quad layout, spkd_quad.hpp / spkd_tri.hpp).
+// The growing-window decision chain (a float state machine with int() truncation,
+// SURVEY.md A-1) runs on the device with the exact operation order of the reference.
+//
+// Sliding window (not on the DIA2 path): prefix snapshots every SNAP_G frames and
+// the row-per-lane layout.
 #pragma once
 #include "spkd_device.hpp"
 #include "spkd_quad.hpp"
@@ -98,94 +103,7 @@ __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long 
     }
 }
 
-// LDS quad record of R(t), built by the whole workgroup (padding lanes untouched:
-// the caller zeroes them once).  The <= G-1 edge frames are staged in LDS first
-// (one coalesced read), then every entry adds its products in frame order.
-// Contains block-wide barriers: call from uniform control flow.
-__device__ __forceinline__ void build_record_lds(double* lds, const double* __restrict__ snap,
-                                                 const float* __restrict__ fr, long long t,
-                                                 double* xs, int tid, int nthreads) {
-    const long long k = t / SNAP_G;
-    const int ne = (int)(t - k * SNAP_G);
-    const float* src = fr + k * SNAP_G * D;
-    for (int idx = tid; idx < ne * D; idx += nthreads) {
-        const int f = idx / D, c = idx - f * D;
-        xs[f * DA + c] = (double)src[idx];
-    }
-    if (tid < ne) xs[tid * DA + D] = 1.0;
-    __syncthreads();
-    const double* s = snap + k * QREC;
-    for (int e = tid; e < QUSE; e += nthreads) {
-        int idx, i, j;
-        quse_decode(e, idx, i, j);
-        double v = s[idx];
-        for (int f = 0; f < ne; ++f) v = fma(xs[f * DA + i], xs[f * DA + j], v);
-        lds[idx] = v;
-    }
-    __syncthreads();
-}
-
-// Quad-layout prefix statistics: DPP row m gets R(tpos) for its own tpos.
-// q = rows (columns 0..38), sv = sums column.  The <= G-1 edge frames of the four
-// positions are first copied to a per-wave LDS buffer (coalesced, few registers),
-// the snapshot rows are loaded straight into the row registers, then the edge
-// frames are added in frame order (positions with fewer edge frames add zeros).
-constexpr int EDGE_FLOATS = (SNAP_G - 1) * D;          // per position (<= G/2 used since snapshots are two-sided)
-constexpr int EDGE_WAVE_FLOATS = 4 * EDGE_FLOATS;      // per wave
-
-__device__ __forceinline__ void quad_prefix_rows(QuadRows& q, double (&sv)[QS],
-                                                 const double* __restrict__ snap,
-                                                 const float* __restrict__ fr, long long tpos,
-                                                 long long nturn, const QuadLane& L,
-                                                 float* edge /* per-wave LDS */) {
-    // nearest snapshot: below (add the frames [G k, t)) or above (subtract [t, G (k+1)))
-    long long k = tpos / SNAP_G;
-    int ne = (int)(tpos - k * SNAP_G);
-    double sgn = 1.0;
-    long long first = k * SNAP_G;                 // first edge frame
-    if (ne > SNAP_G / 2 && (k + 1) * SNAP_G <= nturn) {
-        k += 1;
-        first = tpos;
-        ne = SNAP_G - ne;
-        sgn = -1.0;
-    }
-    const double* s = snap + k * QREC;
-    const int lane = lane_id();
-    // stage the edge frames of the four positions (contiguous floats each)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const long long fm = __shfl(first, 16 * mi);
-        const int nem = __shfl(ne, 16 * mi);
-        const float* src = fr + fm * D;
-        for (int idx = lane; idx < nem * D; idx += WAVE) edge[mi * EDGE_FLOATS + idx] = src[idx];
-    }
-#pragma unroll
-    for (int ss = 0; ss < QS; ++ss) {
-#pragma unroll
-        for (int j = 0; j < tri_cols(ss); ++j) q.r[ss][j] = s[(ss * DA + j) * 16 + L.t];
-        sv[ss] = s[(ss * DA + D) * 16 + L.t];
-    }
-    int mx = ne;
-    mx = max(mx, __shfl_xor(mx, 16));
-    mx = max(mx, __shfl_xor(mx, 32));
-    mx = uniform_i(mx);
-    const float* mine = edge + L.m * EDGE_FLOATS;
-    const bool carrier = L.t < QL;
-#pragma unroll 1
-    for (int e = 0; e < mx; ++e) {
-        double x[QS], cx[QS];
-#pragma unroll
-        for (int ss = 0; ss < QS; ++ss) {
-            const float xf = (carrier && e < ne) ? mine[e * D + QL * ss + (carrier ? L.t : 0)] : 0.0f;
-            x[ss] = (double)xf;
-            cx[ss] = sgn * x[ss];
-            sv[ss] += cx[ss];
-        }
-        TriRank1<0>::run(q, cx, x);
-    }
-}
-
-// Row-per-lane (single matrix) prefix rows, used by KL2 and by the pivoting fallback.
+// Row-per-lane (single matrix) prefix rows from the snapshots (sliding window).
 __device__ __forceinline__ void single_prefix_rows(double (&q)[DA], const double* __restrict__ snap,
                                                    const float* __restrict__ fr, long long t) {
     const long long k = t / SNAP_G;
@@ -262,42 +180,278 @@ __device__ __forceinline__ void log_cand(spkd_cand_log* log, long long cap, unsi
 // which matrix of a split [a, b) | [b, c) a pass forms
 enum { PASS_RIGHT = 0, PASS_LEFT = 1, PASS_GLR = 2, PASS_POOLED = 3 };
 
-// single-matrix form of a pass (fallback / KL2): rows of the moment difference,
-// then covariance (or GLR's weighted covariance)
-__device__ __forceinline__ void single_split_matrix(int pass, const double* ldsRa, const double* ldsRc,
-                                                    const double* __restrict__ snap,
-                                                    const float* __restrict__ fr, long long a,
-                                                    long long b, long long c, double (&q)[DA]) {
-    double ra[DA], rc[DA];
-    if (pass == PASS_POOLED) {
-        single_rows_from_lds(ldsRc, q);
-        single_rows_from_lds(ldsRa, ra);
+// ---------------------------------------------------------------------------
+// Packed lower-triangle record ("tri record") of the augmented moment matrix, in
+// the quad lane layout: line (tri_off(s) + j) holds M(13 s + t, j) for t = 0..12
+// in its first 13 doubles, j < 13 (s + 1); lines 78..80 hold the sums column of
+// slot s; the frame count sits in lane 15 of line 78.  81 lines of 128 B.
+// ---------------------------------------------------------------------------
+constexpr int TLINES = 3 * QL + 3 * QL + 3;                  // 13 + 26 + 39 + 3 = 81
+constexpr int TREC = TLINES * 16;                            // 1 296 doubles = 10 368 B
+constexpr int TREC_SUMS = 6 * QL;                            // first sums line (78)
+constexpr int TREC_COUNT_AT = TREC_SUMS * 16 + 15;
+__host__ __device__ constexpr int tri_off(int s) { return s == 0 ? 0 : (s == 1 ? QL : 3 * QL); }
+
+// entry (row r, column j <= r) of the 40x40 augmented matrix -> index in a tri record
+__device__ __forceinline__ int tri_slot(int r, int j) {
+    if (r < D) { const int s = r / QL; return (tri_off(s) + j) * 16 + (r - QL * s); }
+    if (j < D) { const int s = j / QL; return (TREC_SUMS + s) * 16 + (j - QL * s); }
+    return TREC_COUNT_AT;
+}
+
+// row-per-lane (single matrix) rows of a tri record, by symmetry
+__device__ __forceinline__ void single_rows_from_tri(const double* rec, double (&q)[DA]) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;
 #pragma unroll
-        for (int j = 0; j < DA; ++j) q[j] -= ra[j];
-        cov_rows(q, (double)(c - a));
+    for (int j = 0; j < D; ++j) q[j] = rec[j <= i ? tri_slot(i, j) : tri_slot(j, i)];
+    q[D] = rec[tri_slot(D, i)];
+}
+
+// ---------------------------------------------------------------------------
+// The sweep: threads 0..209 own one 2x2 block of the lower triangle of the 40x40
+// augmented matrix each (column-major over the 20x20 block grid, so that
+// consecutive lanes hold consecutive rows: dumps are half-coalesced).  Per frame a
+// thread reads x[2 bi .. 2 bi + 1] and x[2 bj .. 2 bj + 1] from the float tile and
+// issues four fp64 FMAs.
+// ---------------------------------------------------------------------------
+constexpr int GW_WAVES = 4;
+constexpr int GW_TPB = GW_WAVES * WAVE;
+constexpr int ERR_SWEEP = 16;                                // internal: a wanted position behind the sweep
+constexpr int SW_BLOCKS = 210;
+constexpr int GW_TILE = 128;                                 // frames per LDS tile (float [128][40])
+
+struct SweepLane {
+    int bi, bj;
+    bool on;
+};
+
+__device__ __forceinline__ SweepLane sweep_lane(int tid) {
+    SweepLane s;
+    s.on = tid < SW_BLOCKS;
+    int rem = s.on ? tid : 0, bj = 0;
+    while (rem >= 20 - bj) { rem -= 20 - bj; ++bj; }
+    s.bj = bj;
+    s.bi = bj + rem;
+    return s;
+}
+
+__device__ __forceinline__ void sweep_dump(double* rec, const SweepLane& SL, const double (&acc)[4]) {
+    if (!SL.on) return;
+    const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
+    rec[tri_slot(r0, j0)] = acc[0];
+    if (SL.bi > SL.bj) rec[tri_slot(r0, j0 + 1)] = acc[1];   // above the diagonal otherwise
+    rec[tri_slot(r0 + 1, j0)] = acc[2];
+    rec[tri_slot(r0 + 1, j0 + 1)] = acc[3];
+}
+
+__device__ __forceinline__ void sweep_gather(const double* __restrict__ rec, const SweepLane& SL, double (&acc)[4]) {
+    const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
+    acc[0] = rec[tri_slot(r0, j0)];
+    acc[1] = (SL.bi > SL.bj) ? rec[tri_slot(r0, j0 + 1)] : 0.0;
+    acc[2] = rec[tri_slot(r0 + 1, j0)];
+    acc[3] = rec[tri_slot(r0 + 1, j0 + 1)];
+}
+
+// Adds the turn frames [pos, ...) to acc in frame order.  `want` is the next
+// position at which the caller wants the sums: on_reach(p) is called (uniformly,
+// by all threads) when the sweep stands at p == want, BEFORE frame p is added, and
+// returns the next wanted position (> p), or -1 to stop.  `limit` bounds the
+// frames that may be staged (the last position that will ever be wanted).
+// Frames go through an LDS tile of GW_TILE frames; the loads of the next tile are
+// issued into registers before the current one is consumed, so their latency is
+// covered by the accumulation.  Contains block-wide barriers.
+#ifdef SPKD_PROFILE
+// phase clocks of k_gw (profiling builds only: make libspkd_hip_prof.so)
+__device__ unsigned long long g_gw_prof[12];
+#endif
+constexpr int GW_STAGE = (GW_TILE * D + GW_TPB - 1) / GW_TPB;     // floats per thread per tile (20)
+
+// (branch-free: out-of-range slots re-read element 0; `t` is the caller's opaque copy
+// of the thread index, so that none of this address arithmetic is hoisted out of the
+// scan loop and kept alive -- i.e. spilled -- across the elimination code)
+__device__ __forceinline__ void sweep_issue(const float* __restrict__ fr, long long pos, long long limit,
+                                            int t, float (&st)[GW_STAGE]) {
+    const long long left = limit - pos;
+    const int tl = (int)(left < GW_TILE ? (left < 0 ? 0 : left) : GW_TILE);
+    const float* src = fr + pos * D;
+    const int nfl = tl * D;
+#pragma unroll
+    for (int u = 0; u < GW_STAGE; ++u) {
+        const int idx = t + u * GW_TPB;
+        st[u] = src[idx < nfl ? idx : 0];
+    }
+}
+
+template <class OnReach>
+__device__ __forceinline__ void gw_sweep(const float* __restrict__ fr, float* xs, const SweepLane& SL,
+                                         int tid, double (&acc)[4], long long pos, long long want,
+                                         long long limit, OnReach on_reach, int* err) {
+#ifdef SPKD_PROFILE
+    unsigned long long sw_acc[3] = {0ull, 0ull, 0ull};
+    unsigned long long sw_t = clock64();
+#define SW_TICK(i) do { const unsigned long long now_ = clock64(); sw_acc[i] += now_ - sw_t; sw_t = now_; } while (0)
+#else
+#define SW_TICK(i) ((void)0)
+#endif
+    long long tile0 = pos, tile_end = pos;       // staged frames [tile0, tile_end)
+    int t = tid, bi2 = 2 * SL.bi, bj2 = 2 * SL.bj;
+    asm volatile("" : "+v"(t), "+v"(bi2), "+v"(bj2));
+    const float* xi = xs + bi2;
+    const float* xj = xs + bj2;
+    float st[GW_STAGE];
+    sweep_issue(fr, pos, limit, t, st);
+    for (;;) {
+        if (pos == want) {
+            SW_TICK(0);
+            want = on_reach(pos);
+            SW_TICK(1);
+            if (want < 0) break;
+            continue;
+        }
+        if (want < pos || want > limit) {        // cannot happen; never loop on it
+            if (tid == 0) atomicOr(err, ERR_SWEEP);
+            break;
+        }
+        if (pos >= tile_end) {
+            const int tl = (int)((limit - pos) < GW_TILE ? (limit - pos) : GW_TILE);
+            SW_TICK(0);
+            __syncthreads();                     // the previous tile is no longer read
+            // (slots beyond tl * D hold element 0: they land in tile rows >= tl, never read)
+#pragma unroll
+            for (int u = 0; u < GW_STAGE; ++u) {
+                const int idx = t + u * GW_TPB;
+                const int f = idx / D, c = idx - f * D;
+                if (u < GW_STAGE - 1 || idx < GW_TILE * D) xs[f * DA + c] = st[u];
+            }
+            if (t < GW_TILE) xs[t * DA + D] = 1.0f;
+            __syncthreads();
+            tile0 = pos;
+            tile_end = pos + tl;
+            sweep_issue(fr, tile_end, limit, t, st);         // in flight during the accumulation
+            SW_TICK(2);
+        }
+        const long long stop = want < tile_end ? want : tile_end;
+        const int f1 = (int)(stop - tile0);
+#pragma unroll 4
+        for (int f = (int)(pos - tile0); f < f1; ++f) {
+            const float2 a = *reinterpret_cast<const float2*>(xi + f * DA);
+            const float2 b = *reinterpret_cast<const float2*>(xj + f * DA);
+            const double a0 = (double)a.x, a1 = (double)a.y, b0 = (double)b.x, b1 = (double)b.y;
+            acc[0] = fma(a0, b0, acc[0]);
+            acc[1] = fma(a0, b1, acc[1]);
+            acc[2] = fma(a1, b0, acc[2]);
+            acc[3] = fma(a1, b1, acc[3]);
+        }
+        pos = stop;
+    }
+#ifdef SPKD_PROFILE
+    SW_TICK(0);
+    if (tid == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_gw_prof[8 + i], sw_acc[i]);
+#endif
+}
+
+// The two uses of the sweep, as real functions: compiled apart from the kernel body
+// they keep their few live values in registers.  Inlined into k_gw they share its
+// register allocation with the elimination code, the allocator spills the sweep's
+// loop invariants, and every reload (a scratch load, counted with the global stores
+// in vmcnt) waits for the dump stores in flight -- measured: 6 000 cycles per dump.
+struct SweepOut {
+    long long pos;       // where the persistent sums stand now
+    double next_i;       // i value of the next candidate to build
+};
+
+// coarse scan: P(b_k) -> cache record k for the new candidates k in [built_k, C)
+// (candidate k sits at (long long)(start + i_k), i_k by repeated addition of istep),
+// the persistent sums parked at the last of them, then P(c) -> LDS.
+__device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, double* __restrict__ cache,
+                                                 double start, double istep, double built_i,
+                                                 long long built_k, long long C, long long sweep_pos,
+                                                 long long c, int* err) {
+    extern __shared__ double gw_lds[];
+    double* ldsEnd = gw_lds;
+    double* persist = gw_lds + TREC;
+    float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
+    const int tid = threadIdx.x;
+    const SweepLane SL = sweep_lane(tid);
+    double acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = persist[e * GW_TPB + tid];
+    const long long want = built_k < C ? (long long)(start + built_i) : c;
+    gw_sweep(fr, xs, SL, tid, acc, sweep_pos, want, c, [&](long long pos) -> long long {
+        if (built_k < C) {
+            sweep_dump(cache + built_k * TREC, SL, acc);
+            ++built_k;
+            built_i += istep;
+            if (built_k == C) {             // the sweep rests here until the window grows
+#pragma unroll
+                for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = acc[e];
+                sweep_pos = pos;
+            }
+            return built_k < C ? (long long)(start + built_i) : c;
+        }
+        sweep_dump(ldsEnd, SL, acc);        // pos == c
+        return -1;
+    }, err);
+    SweepOut o;
+    o.pos = sweep_pos;
+    o.next_i = built_i;
+    return o;
+}
+
+// fine scan: P at the F single-frame positions (long long)(start + fine_i0 + k)
+// -> cache records first_slot + k, starting from the sums `base` (a cache record, or
+// nullptr for zero) that stand at base_pos.
+__device__ __noinline__ void gw_sweep_fine(const float* __restrict__ fr, double* __restrict__ cache,
+                                           const double* __restrict__ base, long long base_pos,
+                                           double start, double fine_i0, long long F,
+                                           long long first_slot, int* err) {
+    extern __shared__ double gw_lds[];
+    float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
+    const int tid = threadIdx.x;
+    const SweepLane SL = sweep_lane(tid);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (base) sweep_gather(base, SL, acc);
+    double fx = fine_i0;
+    long long fk = 0;
+    const long long last = (long long)(start + (fine_i0 + (double)(F - 1)));
+    gw_sweep(fr, xs, SL, tid, acc, base_pos, (long long)(start + fx), last, [&](long long) -> long long {
+        sweep_dump(cache + (first_slot + fk) * TREC, SL, acc);
+        ++fk;
+        fx += 1;
+        return fk < F ? (long long)(start + fx) : -1;
+    }, err);
+}
+
+// single-matrix form of a pass (pivoting fallback): P(b) from the candidate's cache
+// record, P(c) from LDS, P(a) = 0
+__device__ __forceinline__ void single_split_matrix(int pass, const double* ldsEnd,
+                                                    const double* __restrict__ rec_b,
+                                                    double n1, double n2, double (&q)[DA]) {
+    const double n = n1 + n2;
+    double rc[DA];
+    if (pass == PASS_POOLED) {
+        single_rows_from_tri(ldsEnd, q);
+        cov_rows(q, n);
         return;
     }
-    single_prefix_rows(q, snap, fr, b);
-    const double n1 = (double)(b - a), n2 = (double)(c - b), n = n1 + n2;
+    single_rows_from_tri(rec_b, q);
+    if (pass == PASS_LEFT) {
+        cov_rows(q, n1);
+        return;
+    }
+    single_rows_from_tri(ldsEnd, rc);
     if (pass == PASS_RIGHT) {
-        single_rows_from_lds(ldsRc, rc);
 #pragma unroll
         for (int j = 0; j < DA; ++j) q[j] = rc[j] - q[j];
         cov_rows(q, n2);
-    } else if (pass == PASS_LEFT) {
-        single_rows_from_lds(ldsRa, ra);
-#pragma unroll
-        for (int j = 0; j < DA; ++j) q[j] -= ra[j];
-        cov_rows(q, n1);
     } else {
-        single_rows_from_lds(ldsRa, ra);
-        single_rows_from_lds(ldsRc, rc);
         const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
         const double be1 = al1 / n1, be2 = al2 / n2;
-        const double s1i = q[D] - ra[D], s2i = rc[D] - q[D];
+        const double s1i = q[D], s2i = rc[D] - q[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            const double q1 = q[j] - ra[j], q2 = rc[j] - q[j];
+            const double q1 = q[j], q2 = rc[j] - q[j];
             const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
             double v = fma(al2, q2, al1 * q1);
             v = fma(-(be1 * s1i), s1j, v);
@@ -306,46 +460,60 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsR
     }
 }
 
-// log det of one pass for the four split points held by the wave (DPP row m: split b).
-// Every pass is the same straight-line code with per-pass coefficients (a switch
-// over differently shaped paths makes the compiler hoist the LDS reads common to
-// several branches above the switch and spill hundreds of registers):
-//     q  = al * R(b) + be * R(a) + ga * R(c)           (moments, rows + sums column)
-//     q += c1 v1^T + c2 v2^T   (al, be, ga, c1 carry the covariance scale f)
-//   right  [b, c): al = -1, be =  0, ga = 1; c1 = -s / n2, v1 = s;  f = 1 / (n2 - 1)
-//   left   [a, b): al =  1, be = -1, ga = 0; c1 = -s / n1, v1 = s;  f = 1 / (n1 - 1)
-//   pooled [a, c): al =  0, be = -1, ga = 1; c1 = -s / N,  v1 = s;  f = 1 / (N - 1)
-//   GLR: al1 (Rb - Ra) + al2 (Rc - Rb) - be1 s1 s1^T - be2 s2 s2^T;  f = 1
-__device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsRa, const double* ldsRc,
-                                                    const double* __restrict__ snap,
-                                                    const float* __restrict__ fr, long long a,
-                                                    long long b, long long c, long long nturn,
-                                                    const QuadLane& L, float* edge, int* err) {
+// log det of one pass for the four split points held by the wave (DPP row m: split
+// b, cache record rec_b).  Every pass is the same straight-line code with per-pass
+// coefficients (a switch over differently shaped paths makes the compiler hoist the
+// LDS reads common to several branches above the switch and spill):
+//     q  = al * P(b) + ga * P(c)                (lower triangle + sums column)
+//     q += c1 v1^T + c2 v2^T   (al, ga, c1 carry the covariance scale f)
+//   right  [b, c): al = -1, ga = 1; v1 = s_c - s_b, c1 = -v1 / n2;  f = 1 / (n2 - 1)
+//   left   [a, b): al =  1, ga = 0; v1 = s_b,       c1 = -v1 / n1;  f = 1 / (n1 - 1)
+//   pooled [a, c): al =  0, ga = 1; v1 = s_c,       c1 = -v1 / N;   f = 1 / (N - 1)
+//   GLR: al1 P(b) + al2 (P(c) - P(b)) - be1 s1 s1^T - be2 s2 s2^T;  f = 1
+__device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsEnd,
+                                                    const double* __restrict__ rec_b,
+                                                    double n1, double n2, const QuadLane& L, int* err) {
     QuadRows q;
     double svb[QS];
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keep the LDS reads out of the callers' loops
-    const double n1 = (double)(b - a), n2 = (double)(c - b), n = n1 + n2;
-    double al, be, ga, f, k1a, k1b, k1c, k2a, k2b, k2c, w1, w2;
-    // v1 = k1a * sb + k1b * sa + k1c * sc ;  c1 = w1 * v1  (same for v2, c2)
+    const double n = n1 + n2;
+    double al, ga, f, k1a, k1c, k2a, k2c, w1, w2;
+    // v1 = k1a * s_b + k1c * s_c ;  c1 = w1 * v1  (same for v2, c2)
     if (pass == PASS_GLR) {
         const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
-        al = al1 - al2; be = -al1; ga = al2; f = 1.0;
-        k1a = 1.0; k1b = -1.0; k1c = 0.0; w1 = -(al1 / n1);
-        k2a = -1.0; k2b = 0.0; k2c = 1.0; w2 = -(al2 / n2);
+        al = al1 - al2; ga = al2; f = 1.0;
+        k1a = 1.0; k1c = 0.0; w1 = -(al1 / n1);
+        k2a = -1.0; k2c = 1.0; w2 = -(al2 / n2);
     } else {
         const double np = pass == PASS_RIGHT ? n2 : (pass == PASS_LEFT ? n1 : n);
         al = pass == PASS_RIGHT ? -1.0 : (pass == PASS_LEFT ? 1.0 : 0.0);
-        be = pass == PASS_RIGHT ? 0.0 : -1.0;
         ga = pass == PASS_LEFT ? 0.0 : 1.0;
         f = 1.0 / (np - 1.0);
-        k1a = al; k1b = be; k1c = ga; w1 = -(f / np);
-        k2a = 0.0; k2b = 0.0; k2c = 0.0; w2 = 0.0;
-        al *= f; be *= f; ga *= f;          // covariance scale folded into the combine
+        k1a = al; k1c = ga; w1 = -(f / np);
+        k2a = 0.0; k2c = 0.0; w2 = 0.0;
+        al *= f; ga *= f;                   // covariance scale folded into the combine
     }
     if (pass != PASS_POOLED) {
-        quad_prefix_rows(q, svb, snap, fr, b, nturn, L, edge);
-    } else {                              // al = 0: R(b) is not part of the pooled window
+        // 81 loads in flight, one latency.  One base pointer per 4 KB (the immediate
+        // offset of a global load spans 4 KB; left to itself the compiler builds a
+        // separate address for every load, spills them and serialises the loads)
+        const double* rt[3];
+        long long o1 = 512, o2 = 1024;      // opaque, so that the bases stay separate registers
+        asm volatile("" : "+v"(o1), "+v"(o2));
+        rt[0] = rec_b + L.t;
+        rt[1] = rt[0] + o1;
+        rt[2] = rt[0] + o2;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+#pragma unroll
+            for (int j = 0; j < tri_cols(s); ++j) {
+                const int line = tri_off(s) + j;
+                q.r[s][j] = rt[line / 32][(line % 32) * 16];
+            }
+            svb[s] = rt[(TREC_SUMS + s) / 32][((TREC_SUMS + s) % 32) * 16];
+        }
+    } else {                                // al = 0: P(b) is not part of the pooled window
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
 #pragma unroll
@@ -358,13 +526,11 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
 #pragma unroll
-        for (int j = 0; j < tri_cols(s); ++j) {
-            const double ra = ldsRa[(s * DA + j) * 16 + ta], rc = ldsRc[(s * DA + j) * 16 + ta];
-            q.r[s][j] = fma(ga, rc, fma(be, ra, al * q.r[s][j]));
-        }
-        const double sa = ldsRa[(s * DA + D) * 16 + ta], sc = ldsRc[(s * DA + D) * 16 + ta];
-        v1[s] = fma(k1c, sc, fma(k1b, sa, k1a * svb[s]));
-        v2[s] = fma(k2c, sc, fma(k2b, sa, k2a * svb[s]));
+        for (int j = 0; j < tri_cols(s); ++j)
+            q.r[s][j] = fma(ga, ldsEnd[(tri_off(s) + j) * 16 + ta], al * q.r[s][j]);
+        const double sc = ldsEnd[(TREC_SUMS + s) * 16 + ta];
+        v1[s] = fma(k1c, sc, k1a * svb[s]);
+        v2[s] = fma(k2c, sc, k2a * svb[s]);
         c1[s] = w1 * v1[s];
         c2[s] = w2 * v2[s];
         __builtin_amdgcn_sched_barrier(0);
@@ -372,39 +538,42 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsR
     TriRank1<0>::run(q, c1, v1);
     if (pass == PASS_GLR) TriRank1<0>::run(q, c2, v2);
     auto form_single = [&](int mi, double (&arr)[DA]) {
-        const long long bm = __shfl(b, 16 * mi);
-        single_split_matrix(pass, ldsRa, ldsRc, snap, fr, a, bm, c, arr);
+        const double* rm = (const double*)__shfl((unsigned long long)rec_b, 16 * mi);
+        single_split_matrix(pass, ldsEnd, rm, __shfl(n1, 16 * mi), __shfl(n2, 16 * mi), arr);
     };
     return tri_logdet(q, L.m, err, form_single);
 }
 
-constexpr int GW_WAVES = 4;
-constexpr int GW_TPB = GW_WAVES * WAVE;
-constexpr int GW_EDGE_BYTES = GW_WAVES * 4 * (SNAP_G - 1) * D * 4;
-constexpr int GW_TILE_BYTES = CD_TILE * DA * 8;
-constexpr int GW_LDS_BYTES = 2 * QREC * 8 + (GW_EDGE_BYTES > GW_TILE_BYTES ? GW_EDGE_BYTES : GW_TILE_BYTES);
+// dynamic LDS: P(c) tri record | the sweep's persistent accumulators | float frame tile
+constexpr int GW_LDS_BYTES = TREC * 8 + 4 * GW_TPB * 8 + GW_TILE * DA * 4;
 
+// Growing window over one VAD turn per workgroup (spk-change-detection.py:180-288):
+// the whole float state machine runs here; outputs are the per-window events.
+//
 // Candidate scratch per slot k: c_i = i value, c_left = memoised left term (BIC:
-// 0.5 N1 log det S1; GLR: log det S1), c_x = right log det / finished distance.
+// 0.5 N1 log det S1; GLR: log det S1), c_x = right log det / finished distance;
+// cache record k = P(b_k).
 //
 // The kernel is one loop over "scans": a coarse scan over the candidates
 // i = minfeas, minfeas + istep, ... (CD:204-221) and, after a positive one, a
 // fine scan over single-frame steps around the maximum (CD:235-251).  Both kinds
 // share one body, so the elimination code exists once.
+#ifdef SPKD_PROFILE
+#define GW_TICK(i) do { const unsigned long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define GW_TICK(i) ((void)0)
+#endif
+
 __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
-        double* __restrict__ snap_all, double* __restrict__ cand_all,
+        double* __restrict__ cache_all, double* __restrict__ cand_all,
         int32_t* __restrict__ n_win, double* __restrict__ win_maxd, int32_t* __restrict__ win_det,
         double* __restrict__ det_start, double* __restrict__ det_maxi, double* __restrict__ det_d,
         double* __restrict__ final_start, spkd_cand_log* clog, long long log_cap,
         unsigned long long* log_count, int* err) {
-    // dynamic LDS (GW_LDS_BYTES): Ra | Rc | per-wave edge buffers; the frame tile of
-    // phase 1 / build_record_lds aliases the edge buffers (never live together)
     extern __shared__ double gw_lds[];
-    double* ldsRa = gw_lds;
-    double* ldsRc = gw_lds + QREC;
-    float* edges = (float*)(gw_lds + 2 * QREC);
-    double* xs = gw_lds + 2 * QREC;
+    double* ldsEnd = gw_lds;                         // P(c), tri record
+    double* persist = gw_lds + TREC;                 // [4][GW_TPB]: the sweep's sums at sweep_pos
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
@@ -413,15 +582,18 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     const int turn = (int)T.id;
     const long long n = T.len;
     const float* fr = frames + T.begin * D;
-    double* snap = snap_all + T.snap_off * QREC;
+    double* cache = cache_all + T.cand_off * TREC;
     const long long cap = T.cand_cap;
     double* c_i = cand_all + 3 * T.cand_off;
     double* c_left = c_i + cap;
     double* c_x = c_left + cap;
 
-    for (int e = tid; e < QREC; e += GW_TPB) { ldsRa[e] = 0.0; ldsRc[e] = 0.0; }
-    build_prefix<GW_TPB>(fr, n, snap, xs);
-    __syncthreads();
+#ifdef SPKD_PROFILE
+    unsigned long long prof_acc[4] = {0ull, 0ull, 0ull, 0ull}, prof_t = clock64(), prof_scans = 0ull;
+#endif
+    for (int e = tid; e < TREC; e += GW_TPB) ldsEnd[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
 
     const int kind = P.kind;
     const double winsize = P.winsize, winstep = P.winstep, rate = P.rate;
@@ -435,7 +607,12 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     long long n_written = 0;         // c_i[0 .. n_written) hold the coarse i sequence
     long long C = 0;                 // coarse candidates of the current scan
     double cur_i = minfeas;          // next i of the coarse sequence for this epoch
-    long long a_cur = -1, c_cur = -1;
+    // the sweep of this epoch: cache records [0, built_k) exist, the persistent sums
+    // stand at frame sweep_pos; built_i = i value of candidate built_k (same repeated
+    // addition as cur_i, so the same doubles)
+    long long built_k = 0, sweep_pos = 0;
+    double built_i = minfeas;
+    long long best_k = 0;
     int nw = 0, nd = 0;
     const double fn = (double)n;
     const double pen_w = P.lambdac * 0.5 * PEN_UNIT;
@@ -443,9 +620,12 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     double maxd = 0.0, maxi = 0.0;   // running maximum (carried from the coarse into the fine scan)
     double fine_i0 = 0.0;
     long long F = 0;
+    __syncthreads();
+    GW_TICK(0);
 
     while (fine || end <= fn) {
         long long base, count;
+        const long long a = (long long)start, c = (long long)end;
         if (!fine) {
             if (nw >= T.ev_cap) { if (tid == 0) atomicOr(err, 4); break; }
             const double lim = end - start - minfeas;
@@ -457,6 +637,11 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             }
             base = 0;
             count = C;
+            // ---- extend the sweep: P(b_k) for the new candidates, then P(c)
+            {
+                const SweepOut so = gw_sweep_coarse(fr, cache, start, istep, built_i, built_k, C, sweep_pos, c, err);
+                if (built_k < C) { sweep_pos = so.pos; built_i = so.next_i; built_k = C; }
+            }
         } else {
             fine_i0 = maxi - istep;
             const double endtune = maxi + istep;
@@ -470,11 +655,16 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             }
             base = C;                // fine-scan scratch sits behind the coarse slots
             count = F;
+            // ---- P at the F single-frame positions: start from a coarse candidate two
+            // steps below the maximum (always at or below the first fine position)
+            if (best_k >= 2)
+                gw_sweep_fine(fr, cache, cache + (best_k - 2) * TREC, (long long)(start + c_i[best_k - 2]),
+                              start, fine_i0, F, C, err);
+            else
+                gw_sweep_fine(fr, cache, nullptr, a, start, fine_i0, F, C, err);
         }
-        const long long a = (long long)start, c = (long long)end;
-        if (a != a_cur) { build_record_lds(ldsRa, snap, fr, a, xs, tid, GW_TPB); a_cur = a; }
-        if (c != c_cur) { build_record_lds(ldsRc, snap, fr, c, xs, tid, GW_TPB); c_cur = c; }
         __syncthreads();
+        GW_TICK(1);
         const double N = (double)(c - a);
         const bool pooled = (kind == SPKD_BIC && !fine);
         if (kind == SPKD_KL2) {
@@ -487,10 +677,12 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 #pragma unroll 1
                 for (int t = 0; t < 2; ++t) {
                     double a_[DA], r_[DA];
-                    single_prefix_rows(a_, snap, fr, b);
-                    single_rows_from_lds(t ? ldsRc : ldsRa, r_);
+                    single_rows_from_tri(cache + (base + job) * TREC, a_);
+                    if (t) {
+                        single_rows_from_tri(ldsEnd, r_);
 #pragma unroll
-                    for (int j = 0; j < DA; ++j) a_[j] = t ? (r_[j] - a_[j]) : (a_[j] - r_[j]);
+                        for (int j = 0; j < DA; ++j) a_[j] = r_[j] - a_[j];
+                    }
                     const double nn = t ? n2 : n1;
                     const double mean_i = a_[D] / nn;
                     cov_rows(a_, nn);
@@ -511,7 +703,8 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 const long long slot = base + k;
                 const double ik = c_i[slot];
                 const long long b = is_pooled ? a : (long long)(start + ik);
-                const double n1 = (double)(b - a), n2 = (double)(c - b);
+                const double n1 = is_pooled ? 0.0 : (double)(b - a);
+                const double n2 = (double)(c - b);
                 const bool need_left = fine || k >= n_memo;
                 const bool any_left = __any(need_left && valid);
                 double lds_[4] = {0.0, 0.0, 0.0, 0.0};
@@ -520,7 +713,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                     if (is_pooled != (p == PASS_POOLED)) continue;
                     if (p == PASS_LEFT && !any_left) continue;
                     if (p == PASS_GLR && kind != SPKD_GLR) continue;
-                    const double v = quad_split_logdet(p, ldsRa, ldsRc, snap, fr, a, b, c, n, L, edges + wave * EDGE_WAVE_FLOATS, err);
+                    const double v = quad_split_logdet(p, ldsEnd, cache + slot * TREC, n1, n2, L, err);
                     if (p == PASS_RIGHT) lds_[0] = v; else if (p == PASS_LEFT) lds_[1] = v;
                     else if (p == PASS_GLR) lds_[2] = v; else lds_[3] = v;
                 }
@@ -543,9 +736,13 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             }
         }
         __syncthreads();
+        GW_TICK(2);
+#ifdef SPKD_PROFILE
+        ++prof_scans;
+#endif
         // ---- finish the distances (BIC): d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
         if (kind == SPKD_BIC) {
-            if (fine) { /* s_ldS still holds the pooled term of this window */ }
+            // (fine scans: s_ldS still holds the pooled term of this window)
             const double ldS = s_ldS;
             const double corr = pen_w * log(N);
             for (long long k = tid; k < count; k += GW_TPB) {
@@ -568,12 +765,14 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                          (w << 32) | (fine ? 0x80000000LL : 0LL) | k, start, c_i[slot], d, b - a, c - b);
             }
         }
+        GW_TICK(3);
         if (!fine) {
             if (C > n_memo) n_memo = C;
             BestD best = block_argmax<GW_WAVES>(c_x, C, NEG_MAXINT_M1, red);
             const bool found = best.k >= 0;
             maxd = best.d;
             maxi = found ? c_i[best.k] : 0.0;
+            best_k = found ? best.k : 0;
             if (tid == 0) {
                 win_maxd[T.ev_off + nw] = found ? maxd : __builtin_nan("");
                 win_det[T.ev_off + nw] = 0;
@@ -610,6 +809,12 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             C = 0;
             cur_i = minfeas;
             start += maxi;
+            // new epoch: the sweep restarts at the new window start
+            built_k = 0;
+            built_i = minfeas;
+            sweep_pos = (long long)start;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
             if (start + winsize * 2 <= fn) {
                 end = start + winsize * 2;
                 ws = minfeas;
@@ -623,6 +828,14 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         n_win[turn] = nw;
         final_start[turn] = start;
     }
+#ifdef SPKD_PROFILE
+    GW_TICK(1);
+    if (tid == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_gw_prof[i], prof_acc[i]);
+        atomicAdd(&g_gw_prof[4], prof_scans);
+        atomicAdd(&g_gw_prof[5], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -109,6 +109,7 @@ spkd_status end_call(spkd_ctx* c) {
     c->kms[0] = c->last_ms;
     for (int i = 1; i < SPKD_N_TIMERS; ++i)
         if (c->kused[i]) HIPCHK(c, hipEventElapsedTime(&c->kms[i], c->ka[i], c->kb[i]));
+    if (herr & ERR_SWEEP) return fail(c, SPKD_EHIP, "internal error: growing-window sweep order");
     if (herr & 4) return fail(c, SPKD_EOVERFLOW, "device scratch capacity exceeded");
     if (herr & ERR_DEGENERATE_MERGE) return fail(c, SPKD_EINVAL, "degenerate merge: a diagonal cell was the minimum");
     if (herr & ERR_NONFINITE) return fail(c, SPKD_ENONFINITE, "array must not contain infs or NaNs");
@@ -562,7 +563,9 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
     TurnDesc* d_turns = nullptr;
     void *d_snap, *d_cand, *d_i32a, *d_i32b, *d_d0, *d_d1, *d_d2, *d_d3, *d_d4, *d_log;
     if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
-    if ((st = scratch(c, S_SNAP, (size_t)n_snap * QREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    // one tri record (running moment sums at the split point) per candidate slot
+    (void)n_snap;
+    if ((st = scratch(c, S_SNAP, (size_t)n_cand * TREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
     if ((st = scratch(c, S_CAND, (size_t)n_cand * 3 * sizeof(double), &d_cand)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32A, (size_t)n_turns * sizeof(int32_t), &d_i32a)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32B, (size_t)n_ev * sizeof(int32_t), &d_i32b)) != SPKD_OK) return st;
@@ -729,3 +732,14 @@ spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t* 
 }
 
 }  // extern "C"
+
+#ifdef SPKD_PROFILE
+// profiling builds only: phase clocks of k_gw since the last call (cycles summed over
+// workgroups: prefix build, scan set-up, log-det jobs, finish + arg-max; scans; turns)
+extern "C" int spkd_debug_gw_prof(unsigned long long* out12) {
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(spkd::g_gw_prof), sizeof z) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(spkd::g_gw_prof), z, sizeof z) != hipSuccess) return 1;
+    return 0;
+}
+#endif

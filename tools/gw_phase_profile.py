@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Where k_gw spends its cycles: runs change detection on a synthetic batch through the
+profiling build of the library (make -C speaker-diarization_amd/csrc libspkd_hip_prof.so)
+and prints the per-phase clocks summed over workgroups.  Development tool only."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = 'speaker-diarization_amd'
+
+
+def main():
+    files_n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    import torch
+    hipabi = importlib.import_module(PKG + '.hipabi')
+    lib = hipabi.load_library(os.path.join(ROOT, PKG, 'csrc', 'libspkd_hip_prof.so'))
+    hipabi._lib = lib                      # every Context of this process uses the profiling build
+    synth = importlib.import_module(PKG + '.synth')
+    pipeline = importlib.import_module(PKG + '.pipeline')
+    rec = importlib.import_module(PKG + '.recipe')
+    sessions = []
+    for i in range(4):
+        feats, vad, _ = synth.make_session(1000003 + i, 3600.0, 4)
+        sessions.append((feats, [(float(rec.py2_float_str(s / 125.0)), float(rec.py2_float_str(e / 125.0)))
+                                 for (s, e) in vad]))
+    T = sessions[0][0].shape[0]
+    frames = torch.from_numpy(np.concatenate([sessions[i % 4][0] for i in range(files_n)])).cuda()
+    files = [pipeline.BatchFile(i * T, T, sessions[i % 4][1]) for i in range(files_n)]
+    ctx = hipabi.Context(0, torch.cuda.current_stream().cuda_stream)
+    out = (C.c_ulonglong * 12)()
+    for it in range(2):
+        tm = {}
+        pipeline.change_detect_batch(ctx, frames.data_ptr(), files_n * T, files, 125.0, pipeline.DIA2_CD, tm)
+        lib.spkd_debug_gw_prof(out)
+        v = list(out)
+        tot = float(sum(v[:4]))
+        print('k_gw %.1f ms; turns %d scans %d; cycles/scan %.0f' % (tm['gw'][-1], v[5], v[4], tot / max(v[4], 1)))
+        for name, x in zip(('prefix build', 'scan set-up', 'log-det jobs', 'finish+argmax'), v[:4]):
+            print('  %-14s %5.1f %%   %8.0f cycles/scan' % (name, 100.0 * x / tot, x / max(v[4], 1)))
+        for name, x in zip(('sweep: accumulate', 'sweep: dumps', 'sweep: staging'), v[8:11]):
+            print('    %-18s %8.0f cycles/scan' % (name, x / max(v[4], 1)))
+
+
+if __name__ == '__main__':
+    main()
