@@ -6,9 +6,10 @@
 // where a[j][k] (row j, column k: lower triangle, not yet touched by step k) is
 // broadcast from its owner lane j % 13 / slot j / 13 with one row_newbcast DPP
 // move -- the symmetric counterpart of broadcasting the pivot row.  Lanes whose
-// rows lie above column j compute into registers nobody reads.  1 144 fp64 FMAs
-// + 780 DPP moves per four determinants (full square form: 1 820 + 741), and
-// 156 VGPRs of matrix instead of 234: two waves per SIMD without column blocking.
+// rows lie above column j compute into registers nobody reads.  The broadcast is the
+// DPP operand of the FMA itself (v_fmac_f64_dpp): 1 144 instructions per four
+// determinants (full square form: 1 820 FMAs + 741 DPP moves), and 156 VGPRs of
+// matrix instead of 234: two waves per SIMD without column blocking.
 #pragma once
 #include "spkd_quad.hpp"
 
@@ -17,14 +18,44 @@ namespace spkd {
 // columns held by slot s: 0 .. tri_cols(s) - 1
 __host__ __device__ constexpr int tri_cols(int s) { return QL * (s + 1); }
 
+// acc += bcast(src, lane T of the DPP row) * m as ONE instruction: gfx950 has the DPP
+// form of v_fmac_f64 for row_newbcast, which the compiler never selects (it emits a
+// v_mov_b64_dpp and a plain FMA: 780 extra instructions per elimination).
+// Hazard: a VALU write of a VGPR needs two wait states before a DPP read of it, and
+// the compiler's hazard recognizer does not look inside inline asm, so the first
+// read of a source in a run carries its own s_nop.  The statements are volatile:
+// their program order is the order the hazard analysis below relies on.
+template <int T, bool NOP>
+__device__ __forceinline__ void fmac_bcast16(double& acc, double src, double m) {
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(m), "n"(T));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(m), "n"(T));
+}
+
+// broadcast with its own wait states (the source may have been written by the asm
+// FMA just before, which the compiler does not see as a VALU write)
+template <int T>
+__device__ __forceinline__ double bcast16_nop(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(r) : "v"(v), "n"(T));
+    return r;
+}
+
+// column J of step K: a[i][J] += l_i * a[J][K].  Every column's first FMA waits
+// (its source a[J][K] was written one step earlier, possibly by the instruction just
+// before when few columns remain).
 template <int K, int J>
 struct TriCol {
     static __device__ __forceinline__ void run(QuadRows& q, const double (&l)[QS]) {
         if constexpr (J < D) {
             constexpr int SJ = J / QL, TJ = J % QL;
-            const double u = bcast16<TJ>(q.r[SJ][K]);            // a[J][K]
+            fmac_bcast16<TJ, true>(q.r[SJ][J], q.r[SJ][K], l[SJ]);
 #pragma unroll
-            for (int s = SJ; s < QS; ++s) q.r[s][J] = fma(l[s], u, q.r[s][J]);
+            for (int s = SJ + 1; s < QS; ++s) fmac_bcast16<TJ, false>(q.r[s][J], q.r[SJ][K], l[s]);
             TriCol<K, J + 1>::run(q, l);
         }
     }
@@ -35,7 +66,7 @@ struct TriStep {
     static __device__ __forceinline__ void run(QuadRows& q, double& det, bool& ok) {
         if constexpr (K < D) {
             constexpr int S = K / QL, T = K % QL;
-            const double piv = bcast16<T>(q.r[S][K]);
+            const double piv = bcast16_nop<T>(q.r[S][K]);
             ok = ok && (piv > 0.0) && (piv < __builtin_huge_val());
             det *= piv;
             const double inv = fast_recip(piv);
@@ -63,9 +94,9 @@ struct TriRank1 {
     static __device__ __forceinline__ void run(QuadRows& q, const double (&c)[QS], const double (&v)[QS]) {
         if constexpr (J < D) {
             constexpr int SJ = J / QL, TJ = J % QL;
-            const double vj = bcast16<TJ>(v[SJ]);
+            fmac_bcast16<TJ, true>(q.r[SJ][J], v[SJ], c[SJ]);
 #pragma unroll
-            for (int s = SJ; s < QS; ++s) q.r[s][J] = fma(c[s], vj, q.r[s][J]);
+            for (int s = SJ + 1; s < QS; ++s) fmac_bcast16<TJ, false>(q.r[s][J], v[SJ], c[s]);
             TriRank1<J + 1>::run(q, c, v);
         }
     }
