@@ -223,6 +223,11 @@ spkd_status spkd_ahc(spkd_ctx *ctx, const double *d_stats, const int64_t *h_seg_
 void spkd_py2_roundtrip(double *h_values, int64_t n);
 spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t *h_a,
                                     const int32_t *h_b, int32_t *h_labels);
+/* the same for n_problems merge logs laid out like spkd_ahc's outputs (problem p:
+ * records h_seg_off[p] .. h_seg_off[p+1], merges at h_seg_off[p] + m) */
+spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t *h_seg_off,
+                                          const int32_t *h_n_merges, const int32_t *h_a,
+                                          const int32_t *h_b, int32_t *h_labels);
 
 #ifdef __cplusplus
 }

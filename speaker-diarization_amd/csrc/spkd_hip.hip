@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -421,7 +422,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     // one workgroup per problem fills the chip only when there are many problems;
     // with few, the merge loop runs as a chain of launches over all CUs instead
     int path = P->path;
-    if (path != SPKD_AHC_MONO && path != SPKD_AHC_WIDE) path = n_prob <= 128 ? SPKD_AHC_WIDE : SPKD_AHC_MONO;
+    if (path != SPKD_AHC_MONO && path != SPKD_AHC_WIDE) path = n_prob <= 64 ? SPKD_AHC_WIDE : SPKD_AHC_MONO;
     const size_t lds = (size_t)(n_max + 4) * sizeof(int32_t);
     if (path == SPKD_AHC_MONO && lds > 150 * 1024) path = SPKD_AHC_WIDE;
     if (path == SPKD_AHC_MONO) {
@@ -714,21 +715,56 @@ void spkd_py2_roundtrip(double* v, int64_t n) {
 spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t* h_a, const int32_t* h_b,
                                     int32_t* h_labels) {
     if (n < 0 || n_merges < 0 || (n > 0 && !h_labels) || (n_merges > 0 && (!h_a || !h_b))) return SPKD_EINVAL;
-    // cluster_of[i]: position (in the shrinking list) of record i's cluster
-    std::vector<int32_t> pos((size_t)n);
-    for (int64_t i = 0; i < n; ++i) pos[(size_t)i] = (int32_t)i;
+    // ids: the shrinking list of clusters (by representative record); a merge folds
+    // list entry b into entry a and closes the gap, like speakers[a].extend(speakers.pop(b))
+    std::vector<int32_t> ids((size_t)n), parent((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = parent[(size_t)i] = (int32_t)i;
     int64_t m = n;
     for (int64_t k = 0; k < n_merges; ++k) {
         const int32_t a = h_a[k], b = h_b[k];
         if (a < 0 || b <= a || b >= m) return SPKD_EINVAL;
-        for (int64_t i = 0; i < n; ++i) {
-            int32_t& p = pos[(size_t)i];
-            if (p == b) p = a; else if (p > b) --p;
-        }
+        parent[(size_t)ids[(size_t)b]] = ids[(size_t)a];
+        ids.erase(ids.begin() + b);
         --m;
     }
-    for (int64_t i = 0; i < n; ++i) h_labels[i] = pos[(size_t)i] + 1;
+    // final position of every surviving representative, then path-compressing finds
+    std::vector<int32_t> where((size_t)n, -1);
+    for (int64_t p = 0; p < m; ++p) where[(size_t)ids[(size_t)p]] = (int32_t)p;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t r = (int32_t)i;
+        while (parent[(size_t)r] != r) r = parent[(size_t)r];
+        int32_t c = (int32_t)i;
+        while (parent[(size_t)c] != r) { const int32_t nx = parent[(size_t)c]; parent[(size_t)c] = r; c = nx; }
+        h_labels[i] = where[(size_t)r] + 1;
+    }
     return SPKD_OK;
+}
+
+spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t* h_seg_off, const int32_t* h_n_merges,
+                                          const int32_t* h_a, const int32_t* h_b, int32_t* h_labels) {
+    if (n_problems < 0 || (n_problems > 0 && (!h_seg_off || !h_n_merges || !h_a || !h_b || !h_labels)))
+        return SPKD_EINVAL;
+    std::atomic<int> bad{0};
+    auto work = [&](int64_t lo, int64_t hi) {
+        for (int64_t p = lo; p < hi; ++p) {
+            const int64_t o = h_seg_off[p];
+            if (spkd_labels_from_merges(h_seg_off[p + 1] - o, h_n_merges[p], h_a + o, h_b + o, h_labels + o) != SPKD_OK)
+                bad.store(1);
+        }
+    };
+    const int nthreads = (int)std::min<int64_t>(8, n_problems / 16);
+    if (nthreads <= 1) {
+        work(0, n_problems);
+    } else {
+        std::vector<std::thread> pool;
+        const int64_t step = (n_problems + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t) {
+            const int64_t lo = t * step, hi = std::min<int64_t>(n_problems, lo + step);
+            if (lo < hi) pool.emplace_back(work, lo, hi);
+        }
+        for (auto& th : pool) th.join();
+    }
+    return bad.load() ? SPKD_EINVAL : SPKD_OK;
 }
 
 }  // extern "C"

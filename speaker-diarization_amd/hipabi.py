@@ -21,7 +21,7 @@ EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_destroy', 'spkd_last_error',
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
            'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw', 'spkd_gw_ex',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
-           'spkd_labels_from_merges']
+           'spkd_labels_from_merges', 'spkd_labels_from_merges_batch']
 
 
 class CdParams(C.Structure):
@@ -93,6 +93,7 @@ def load_library(path=None):
     lib.spkd_py2_roundtrip.argtypes = [vp, i64]
     lib.spkd_py2_roundtrip.restype = None
     lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
+    lib.spkd_labels_from_merges_batch.argtypes = [i64, vp, vp, vp, vp, vp]
     if lib.spkd_abi_version() != 1:
         raise ImportError('libspkd_hip.so ABI version mismatch')
     if path is None:
@@ -117,6 +118,21 @@ def labels_from_merges(n, a, b):
     b = np.ascontiguousarray(b, dtype=np.int32)
     out = np.zeros(n, dtype=np.int32)
     st = load_library().spkd_labels_from_merges(n, len(a), _ptr(a), _ptr(b), _ptr(out))
+    if st != SPKD_OK:
+        raise SpkdError(st, 'bad merge log')
+    return out
+
+
+def labels_from_merges_batch(seg_off, n_merges, a, b):
+    """Final 1-based cluster index of every record of every problem of an spkd_ahc
+    result (same layout as its outputs)."""
+    seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+    n_merges = np.ascontiguousarray(n_merges, dtype=np.int32)
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    out = np.zeros(int(seg_off[-1]), dtype=np.int32)
+    st = load_library().spkd_labels_from_merges_batch(len(seg_off) - 1, _ptr(seg_off), _ptr(n_merges),
+                                                      _ptr(a), _ptr(b), _ptr(out))
     if st != SPKD_OK:
         raise SpkdError(st, 'bad merge log')
     return out
@@ -197,10 +213,20 @@ class Context(object):
         return self.check(st, allow=(SPKD_ENONFINITE,))
 
     # ---- (3)
-    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096, tight=False):
+    def _buf(self, name, n, dtype):
+        """Host output buffer reused across calls (fresh pages cost more than the copy)."""
+        cache = self.__dict__.setdefault('_bufs', {})
+        arr = cache.get(name)
+        if arr is None or arr.shape[0] < n or arr.dtype != np.dtype(dtype):
+            arr = cache[name] = np.empty(max(n, 1), dtype=dtype)
+        return arr[:n]
+
+    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096, tight=False, reuse=False):
         """tight=True sizes the event arrays for the typical case (a quarter of the
         guaranteed bound) and transparently repeats the call with the full bound if
-        the device reports an overflow -- four times less data to allocate and copy."""
+        the device reports an overflow -- four times less data to allocate and copy.
+        reuse=True returns views of per-context buffers: valid until the next gw call
+        on this context."""
         b = np.ascontiguousarray(begins, dtype=np.int64)
         e = np.ascontiguousarray(ends, dtype=np.int64)
         nt = len(b)
@@ -213,13 +239,14 @@ class Context(object):
             off = np.zeros(nt + 1, dtype=np.int64)
             off[1:] = np.cumsum(caps)
             nev = int(off[-1])
-            n_win = np.empty(nt, dtype=np.int32)
-            win_maxd = np.empty(nev, dtype=np.float64)
-            win_det = np.empty(nev, dtype=np.int32)
-            det_start = np.empty(nev, dtype=np.float64)
-            det_maxi = np.empty(nev, dtype=np.float64)
-            det_d = np.empty(nev, dtype=np.float64)
-            final_start = np.empty(nt, dtype=np.float64)
+            mk = self._buf if reuse else (lambda name, n, dt: np.empty(n, dtype=dt))
+            n_win = mk('n_win', nt, np.int32)
+            win_maxd = mk('win_maxd', nev, np.float64)
+            win_det = mk('win_det', nev, np.int32)
+            det_start = mk('det_start', nev, np.float64)
+            det_maxi = mk('det_maxi', nev, np.float64)
+            det_d = mk('det_d', nev, np.float64)
+            final_start = mk('final_start', nt, np.float64)
             log = (CandLog * max(log_cap, 1))()
             cnt = C.c_int64(0)
             st = self.lib.spkd_gw_ex(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,

@@ -52,7 +52,7 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
                         float(np.floor(cd['winsize_s'] * rate)), float(np.floor(cd['winstep_s'] * rate)),
                         float(np.floor(rate * cd['deltaws_s'])), rate)
     _t1 = time.perf_counter()
-    r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096, tight=True)
+    r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096, tight=True, reuse=True)
     _t2 = time.perf_counter()
     if timings is not None:
         timings.setdefault('gw', []).append(ctx.last_ms('gw'))
@@ -139,13 +139,15 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
         ctx.dev_free(d_stats)
     if r['status'] == hipabi.SPKD_ENONFINITE:
         raise ValueError('array must not contain infs or NaNs')
+    all_labels = hipabi.labels_from_merges_batch(seg_off, r['n_merges'], r['a'], r['b'])
     out = []
     for fi in range(len(files)):
         o, c = int(seg_off[fi]), cnt[fi]
-        nm = int(r['n_merges'][fi])
-        a, bb, d = r['a'][o:o + nm], r['b'][o:o + nm], r['d'][o:o + nm]
-        labels = hipabi.labels_from_merges(c, a, bb)
-        out.append((labels, list(zip(a.tolist(), bb.tolist(), d.tolist())) if want_merges else None))
+        merges = None
+        if want_merges:
+            nm = int(r['n_merges'][fi])
+            merges = list(zip(r['a'][o:o + nm].tolist(), r['b'][o:o + nm].tolist(), r['d'][o:o + nm].tolist()))
+        out.append((all_labels[o:o + c], merges))
     if timings is not None:
         _t4 = time.perf_counter()
         timings.setdefault('wall_cl_prepare', []).append(1e3 * (_t1 - _t0))
@@ -160,12 +162,17 @@ def diarize_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, cl
     [start_s, end_s, speaker] in recipe order."""
     segs = change_detect_batch(ctx, d_frames, total_frames, files, rate, cd, timings)
     res = cluster_batch(ctx, d_frames, total_frames, files, segs, rate, cl, timings)
-    out = []
-    for s, (labels, _) in zip(segs, res):
-        # recipe order of spk_cluster_hi's output: sorted by (start*rate, end*rate, line)
-        if len(s) == 0:
-            out.append(np.zeros((0, 3)))
-            continue
-        order = np.lexsort((np.arange(len(s)), s[:, 1] * rate, s[:, 0] * rate))
-        out.append(np.column_stack([s[order], labels[order].astype(np.float64)]))
+    # recipe order of spk_cluster_hi's output: per file, sorted by (start*rate, end*rate, line)
+    cnt = [len(s) for s in segs]
+    n = sum(cnt)
+    if n == 0:
+        return [np.zeros((0, 3)) for _ in segs]
+    allseg = np.concatenate([np.asarray(s, dtype=np.float64).reshape(-1, 2) for s in segs])
+    labels = np.concatenate([lab for (lab, _) in res]).astype(np.float64)
+    owner = np.repeat(np.arange(len(segs)), cnt)
+    order = np.lexsort((np.arange(n), allseg[:, 1] * rate, allseg[:, 0] * rate, owner))
+    rows = np.column_stack([allseg[order], labels[order]])
+    bounds = np.zeros(len(segs) + 1, dtype=np.int64)
+    bounds[1:] = np.cumsum(cnt)
+    out = [rows[bounds[i]:bounds[i + 1]] for i in range(len(segs))]
     return out

@@ -170,3 +170,39 @@ def test_labels_from_merges_helper():
         for i in c:
             want[i] = k + 1
     assert hipabi.labels_from_merges(n, a_list, b_list).tolist() == want
+
+
+def test_labels_from_merges_batch_matches_the_replay():
+    """The batch form on ragged problems (spkd_ahc's output layout), against a literal
+    replay of speakers[a].extend(speakers[b]); speakers.pop(b) (spk-clustering.py:216-217)."""
+    hipabi = pkg('hipabi')
+    import random
+    random.seed(11)
+    sizes = [1, 2, 57, 0, 300, 5] * 8
+    seg_off = np.zeros(len(sizes) + 1, dtype=np.int64)
+    seg_off[1:] = np.cumsum(sizes)
+    a_all = np.zeros(int(seg_off[-1]), dtype=np.int32)
+    b_all = np.zeros(int(seg_off[-1]), dtype=np.int32)
+    n_merges = np.zeros(len(sizes), dtype=np.int32)
+    want = np.zeros(int(seg_off[-1]), dtype=np.int32)
+    for p, n in enumerate(sizes):
+        clusters = [[i] for i in range(n)]
+        nm = random.randrange(0, n) if n > 1 else 0
+        for k in range(nm):
+            m = len(clusters)
+            a = random.randrange(m - 1)
+            b = random.randrange(a + 1, m)
+            a_all[seg_off[p] + k] = a
+            b_all[seg_off[p] + k] = b
+            clusters[a].extend(clusters[b])
+            clusters.pop(b)
+        n_merges[p] = nm
+        for k, c in enumerate(clusters):
+            for i in c:
+                want[seg_off[p] + i] = k + 1
+    got = hipabi.labels_from_merges_batch(seg_off, n_merges, a_all, b_all)
+    assert np.array_equal(got, want)
+    for p, n in enumerate(sizes):
+        o, nm = int(seg_off[p]), int(n_merges[p])
+        one = hipabi.labels_from_merges(n, a_all[o:o + nm], b_all[o:o + nm])
+        assert np.array_equal(one, want[o:o + n])
