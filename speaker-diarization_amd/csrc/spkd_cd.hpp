@@ -460,17 +460,20 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
     }
 }
 
-// log det of one pass for the four split points held by the wave (DPP row m: split
-// b, cache record rec_b).  Every pass is the same straight-line code with per-pass
-// coefficients (a switch over differently shaped paths makes the compiler hoist the
-// LDS reads common to several branches above the switch and spill):
+// log det of four (pass, split point) items held by the wave: DPP row m forms the
+// matrix of ITS pass for ITS split b (cache record rec_b) -- the passes of a scan
+// are packed four to a wave whatever their kind, so `pass` is a per-lane value and
+// everything below is straight-line code with per-lane coefficients:
 //     q  = al * P(b) + ga * P(c)                (lower triangle + sums column)
 //     q += c1 v1^T + c2 v2^T   (al, ga, c1 carry the covariance scale f)
 //   right  [b, c): al = -1, ga = 1; v1 = s_c - s_b, c1 = -v1 / n2;  f = 1 / (n2 - 1)
 //   left   [a, b): al =  1, ga = 0; v1 = s_b,       c1 = -v1 / n1;  f = 1 / (n1 - 1)
 //   pooled [a, c): al =  0, ga = 1; v1 = s_c,       c1 = -v1 / N;   f = 1 / (N - 1)
+//                  (rec_b: any valid record, it is multiplied by zero)
 //   GLR: al1 P(b) + al2 (P(c) - P(b)) - be1 s1 s1^T - be2 s2 s2^T;  f = 1
-__device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsEnd,
+// two: the launch has GLR items (wave-uniform; the second rank-one term is skipped
+// otherwise).
+__device__ __forceinline__ double quad_split_logdet(int pass, bool two, const double* ldsEnd,
                                                     const double* __restrict__ rec_b,
                                                     double n1, double n2, const QuadLane& L, int* err) {
     QuadRows q;
@@ -478,23 +481,25 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsE
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keep the LDS reads out of the callers' loops
     const double n = n1 + n2;
-    double al, ga, f, k1a, k1c, k2a, k2c, w1, w2;
+    double al, ga, k1a, k1c, k2a, k2c, w1, w2;
     // v1 = k1a * s_b + k1c * s_c ;  c1 = w1 * v1  (same for v2, c2)
-    if (pass == PASS_GLR) {
-        const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
-        al = al1 - al2; ga = al2; f = 1.0;
-        k1a = 1.0; k1c = 0.0; w1 = -(al1 / n1);
-        k2a = -1.0; k2c = 1.0; w2 = -(al2 / n2);
-    } else {
+    {
+        const bool glr = pass == PASS_GLR;
+        const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);     // GLR lanes only
         const double np = pass == PASS_RIGHT ? n2 : (pass == PASS_LEFT ? n1 : n);
-        al = pass == PASS_RIGHT ? -1.0 : (pass == PASS_LEFT ? 1.0 : 0.0);
-        ga = pass == PASS_LEFT ? 0.0 : 1.0;
-        f = 1.0 / (np - 1.0);
-        k1a = al; k1c = ga; w1 = -(f / np);
-        k2a = 0.0; k2c = 0.0; w2 = 0.0;
-        al *= f; ga *= f;                   // covariance scale folded into the combine
+        const double f = 1.0 / (np - 1.0);
+        const double sa = pass == PASS_RIGHT ? -1.0 : (pass == PASS_LEFT ? 1.0 : 0.0);
+        const double sg = pass == PASS_LEFT ? 0.0 : 1.0;
+        al = glr ? al1 - al2 : sa * f;      // covariance scale folded into the combine
+        ga = glr ? al2 : sg * f;
+        k1a = glr ? 1.0 : sa;
+        k1c = glr ? 0.0 : sg;
+        w1 = glr ? -(al1 / n1) : -(f / np);
+        k2a = glr ? -1.0 : 0.0;
+        k2c = glr ? 1.0 : 0.0;
+        w2 = glr ? -(al2 / n2) : 0.0;
     }
-    if (pass != PASS_POOLED) {
+    {
         // 81 loads in flight, one latency.  One base pointer per 4 KB (the immediate
         // offset of a global load spans 4 KB; left to itself the compiler builds a
         // separate address for every load, spills them and serialises the loads)
@@ -513,13 +518,6 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsE
             }
             svb[s] = rt[(TREC_SUMS + s) / 32][((TREC_SUMS + s) % 32) * 16];
         }
-    } else {                                // al = 0: P(b) is not part of the pooled window
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-#pragma unroll
-            for (int j = 0; j < tri_cols(s); ++j) q.r[s][j] = 0.0;
-            svb[s] = 0.0;
-        }
     }
     __builtin_amdgcn_sched_barrier(0);
     double v1[QS], v2[QS], c1[QS], c2[QS];
@@ -536,10 +534,10 @@ __device__ __forceinline__ double quad_split_logdet(int pass, const double* ldsE
         __builtin_amdgcn_sched_barrier(0);
     }
     TriRank1<0>::run(q, c1, v1);
-    if (pass == PASS_GLR) TriRank1<0>::run(q, c2, v2);
+    if (two) TriRank1<0>::run(q, c2, v2);
     auto form_single = [&](int mi, double (&arr)[DA]) {
         const double* rm = (const double*)__shfl((unsigned long long)rec_b, 16 * mi);
-        single_split_matrix(pass, ldsEnd, rm, __shfl(n1, 16 * mi), __shfl(n2, 16 * mi), arr);
+        single_split_matrix(__shfl(pass, 16 * mi), ldsEnd, rm, __shfl(n1, 16 * mi), __shfl(n2, 16 * mi), arr);
     };
     return tri_logdet(q, L.m, err, form_single);
 }
@@ -584,14 +582,18 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     const float* fr = frames + T.begin * D;
     double* cache = cache_all + T.cand_off * TREC;
     const long long cap = T.cand_cap;
-    double* c_i = cand_all + 3 * T.cand_off;
+    double* c_i = cand_all + 4 * T.cand_off;
     double* c_left = c_i + cap;
     double* c_x = c_left + cap;
+    double* c_w = c_x + cap;             // GLR: log det of the pooled-within matrix
 
 #ifdef SPKD_PROFILE
     unsigned long long prof_acc[4] = {0ull, 0ull, 0ull, 0ull}, prof_t = clock64(), prof_scans = 0ull;
 #endif
-    for (int e = tid; e < TREC; e += GW_TPB) ldsEnd[e] = 0.0;
+    for (int e = tid; e < TREC; e += GW_TPB) {
+        ldsEnd[e] = 0.0;
+        cache[e] = 0.0;              // record 0 is read (times zero) by the pooled item even before it is built
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
 
@@ -692,46 +694,37 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 if (lane == 0) c_x[base + job] = dist;
             }
         } else {
-            // quad jobs: job -1 = pooled window (BIC coarse scans), then groups of 4 split
-            // points; ONE call site of the elimination for all passes (code size)
-            const long long nquads = (count + 3) / 4;
-            for (long long job = (long long)wave - (pooled ? 1 : 0); job < nquads; job += GW_WAVES) {
-                const bool is_pooled = job < 0;
-                long long k = is_pooled ? 0 : 4 * job + L.m;
-                const bool valid = is_pooled ? false : (k < count);
-                k = (k < count) ? k : count - 1;
+            // the scan's matrices as one list of (pass, candidate) items, four to a wave
+            // whatever their kind: [pooled window] (BIC coarse scans) | right of every
+            // candidate | left of the candidates not memoised yet | GLR's W of every candidate
+            const long long n_pool = pooled ? 1 : 0;
+            const long long left0 = fine ? 0 : (n_memo < count ? n_memo : count);
+            const long long n_left = count - left0;
+            const bool glr_kind = kind == SPKD_GLR;
+            const long long M = n_pool + count + n_left + (glr_kind ? count : 0);
+            for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
+                long long it = 4 * q4 + L.m;
+                const bool valid = it < M;
+                it = valid ? it : M - 1;
+                int pass;
+                long long k;
+                if (it < n_pool) { pass = PASS_POOLED; k = 0; }
+                else if (it < n_pool + count) { pass = PASS_RIGHT; k = it - n_pool; }
+                else if (it < n_pool + count + n_left) { pass = PASS_LEFT; k = left0 + (it - n_pool - count); }
+                else { pass = PASS_GLR; k = it - n_pool - count - n_left; }
                 const long long slot = base + k;
-                const double ik = c_i[slot];
-                const long long b = is_pooled ? a : (long long)(start + ik);
-                const double n1 = is_pooled ? 0.0 : (double)(b - a);
-                const double n2 = (double)(c - b);
-                const bool need_left = fine || k >= n_memo;
-                const bool any_left = __any(need_left && valid);
-                double lds_[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-                for (int p = 0; p < 4; ++p) {
-                    if (is_pooled != (p == PASS_POOLED)) continue;
-                    if (p == PASS_LEFT && !any_left) continue;
-                    if (p == PASS_GLR && kind != SPKD_GLR) continue;
-                    const double v = quad_split_logdet(p, ldsEnd, cache + slot * TREC, n1, n2, L, err);
-                    if (p == PASS_RIGHT) lds_[0] = v; else if (p == PASS_LEFT) lds_[1] = v;
-                    else if (p == PASS_GLR) lds_[2] = v; else lds_[3] = v;
-                }
-                if (is_pooled) {
-                    if (lane == 0) s_ldS = lds_[3];
-                    continue;
-                }
-                const double ld_right = lds_[0], ld_left = lds_[1], ld_w = lds_[2];
+                // (no candidates at all: the only item is the pooled window; record 0 is still a
+                // finite record of this or an earlier epoch, or zero-initialised scratch)
+                const double ik = count > 0 ? c_i[slot] : 0.0;
+                const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
+                const double n1 = (double)(b - a), n2 = (double)(c - b);
+                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * TREC, n1, n2, L, err);
                 if (valid && L.t == 0) {
-                    if (kind == SPKD_BIC) {
-                        // left term: 0.5 N1 log det S1, memoised per i inside an epoch (CD:84-90)
-                        if (need_left) c_left[slot] = 0.5 * n1 * ld_left;
-                        c_x[slot] = ld_right;
-                    } else {
-                        const double l1 = need_left ? ld_left : c_left[slot];
-                        if (need_left && !fine) c_left[slot] = l1;
-                        c_x[slot] = -(N / 2.0) * ((n1 / N) * l1 + (n2 / N) * ld_right - ld_w);
-                    }
+                    if (pass == PASS_POOLED) s_ldS = v;
+                    else if (pass == PASS_RIGHT) c_x[slot] = v;
+                    // left term, memoised per i inside an epoch (CD:84-90): BIC 0.5 N1 log det S1
+                    else if (pass == PASS_LEFT) c_left[slot] = glr_kind ? v : 0.5 * n1 * v;
+                    else c_w[slot] = v;
                 }
             }
         }
@@ -740,7 +733,17 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 #ifdef SPKD_PROFILE
         ++prof_scans;
 #endif
-        // ---- finish the distances (BIC): d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
+        // ---- finish the distances.  GLR: -(N/2) ((N1/N) log|S1| + (N2/N) log|S2| - log|W|)
+        if (kind == SPKD_GLR) {
+            for (long long k = tid; k < count; k += GW_TPB) {
+                const long long slot = base + k;
+                const long long b = (long long)(start + c_i[slot]);
+                const double n1 = (double)(b - a), n2 = (double)(c - b);
+                c_x[slot] = -(N / 2.0) * ((n1 / N) * c_left[slot] + (n2 / N) * c_x[slot] - c_w[slot]);
+            }
+            __syncthreads();
+        }
+        // BIC: d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
         if (kind == SPKD_BIC) {
             // (fine scans: s_ldS still holds the pooled term of this window)
             const double ldS = s_ldS;

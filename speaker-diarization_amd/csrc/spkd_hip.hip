@@ -567,7 +567,7 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
     // one tri record (running moment sums at the split point) per candidate slot
     (void)n_snap;
     if ((st = scratch(c, S_SNAP, (size_t)n_cand * TREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
-    if ((st = scratch(c, S_CAND, (size_t)n_cand * 3 * sizeof(double), &d_cand)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_CAND, (size_t)n_cand * 4 * sizeof(double), &d_cand)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32A, (size_t)n_turns * sizeof(int32_t), &d_i32a)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32B, (size_t)n_ev * sizeof(int32_t), &d_i32b)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_D0, (size_t)n_ev * sizeof(double), &d_d0)) != SPKD_OK) return st;
