@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic sessions (tiled to --files)')
     ap.add_argument('--seconds', type=float, default=3600.0)
     ap.add_argument('--speakers', type=int, default=4)
-    ap.add_argument('--cpu-sample-seconds', type=float, default=420.0)
+    ap.add_argument('--cpu-sample-seconds', type=float, default=1800.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ahc-path', type=int, default=0, help='0 auto, 1 one workgroup per file, 2 chained launches')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
@@ -182,7 +182,7 @@ def main():
         # calibrated on k_chunk_stats, whose read volume is known exactly) -- only valid
         # for the workload those passes were taken on
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01c_bench256_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r01d_bench256_hbm_traffic.json')
         if (args.files, args.seconds, args.speakers) == (256, 3600.0, 4) and os.path.exists(tfile):
             with open(tfile) as f:
                 tk = json.load(f)['kernels'].get(dom)
