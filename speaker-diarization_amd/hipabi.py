@@ -152,6 +152,8 @@ class Context(object):
 
     def close(self):
         if getattr(self, 'h', None):
+            for ptr, _ in self.__dict__.pop('_dev_scratch', {}).values():
+                self.lib.spkd_free(self.h, C.c_void_p(ptr))
             self.lib.spkd_destroy(self.h)
             self.h = None
 
@@ -180,6 +182,18 @@ class Context(object):
     def dev_free(self, ptr):
         if ptr:
             self.check(self.lib.spkd_free(self.h, C.c_void_p(ptr)))
+
+    def dev_scratch(self, name, nbytes):
+        """Device buffer kept by the context and reused by later calls under the same
+        name (hipMalloc / hipFree of a batch-sized buffer cost milliseconds each)."""
+        cache = self.__dict__.setdefault('_dev_scratch', {})
+        ptr, cap = cache.get(name, (None, 0))
+        if ptr is None or cap < nbytes:
+            if ptr is not None:
+                self.dev_free(ptr)
+            ptr, cap = self.dev_alloc(nbytes), nbytes
+            cache[name] = (ptr, cap)
+        return ptr
 
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)

@@ -62,10 +62,11 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
         raise ValueError('array must not contain infs or NaNs')
     off = r['off']
     nt = len(tb)
-    caps = np.diff(off)
-    turn_of = np.repeat(np.arange(nt), caps)
-    within = (np.arange(int(off[-1])) - off[turn_of]) < r['n_win'][turn_of]
-    nd = np.bincount(turn_of[within & (r['win_det'] == 1)], minlength=nt)     # detections per turn
+    # detections per turn = ones among the turn's n_win window flags (whatever lies behind
+    # them in the reused buffers cancels in the difference of the running sums)
+    cs = np.zeros(int(off[-1]) + 1, dtype=np.int64)
+    np.cumsum(r['win_det'], dtype=np.int64, out=cs[1:])
+    nd = cs[off[:-1] + r['n_win']] - cs[off[:-1]]
     # detection j of turn t sits at off[t] + j
     tot = int(nd.sum())
     det_turn = np.repeat(np.arange(nt), nd)
@@ -113,30 +114,27 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
     a0 = np.clip((allseg[:, 0] * rate).astype(np.int64), 0, fn)
     a1 = np.maximum(a0, np.clip((allseg[:, 1] * rate).astype(np.int64), 0, fn))
     b, e = foff + a0, foff + a1
-    d_stats = ctx.dev_alloc(max(n, 1) * hipabi.REC * 8)
+    d_stats = ctx.dev_scratch('segment_stats', max(n, 1) * hipabi.REC * 8)
     _t1 = time.perf_counter()
-    try:
-        ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
-        _t2 = time.perf_counter()
-        if timings is not None:
-            timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
-            timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
-            timings['stats_frames'] = int((e - b).sum())
-            timings['stats_sets'] = n
-        p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], cl.get('path', 0),
-                             cl['lambdac'], cl['threshold'])
-        r = ctx.ahc(d_stats, seg_off, p)
-        _t3 = time.perf_counter()
-        if timings is not None:
-            for k in ('cluster_prep', 'matrix', 'ahc'):
-                timings.setdefault(k, []).append(ctx.last_ms(k))
-            npb = np.diff(seg_off)
-            nm = r['n_merges'].astype(np.int64)
-            timings['matrix_pairs'] = int((npb * (npb - 1) // 2).sum())
-            # merge m of a problem with N records recomputes N - 2 - m distances
-            timings['ahc_pairs'] = int((nm * (npb - 2) - nm * (nm - 1) // 2).sum())
-    finally:
-        ctx.dev_free(d_stats)
+    ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
+    _t2 = time.perf_counter()
+    if timings is not None:
+        timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
+        timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
+        timings['stats_frames'] = int((e - b).sum())
+        timings['stats_sets'] = n
+    p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], cl.get('path', 0),
+                         cl['lambdac'], cl['threshold'])
+    r = ctx.ahc(d_stats, seg_off, p)
+    _t3 = time.perf_counter()
+    if timings is not None:
+        for k in ('cluster_prep', 'matrix', 'ahc'):
+            timings.setdefault(k, []).append(ctx.last_ms(k))
+        npb = np.diff(seg_off)
+        nm = r['n_merges'].astype(np.int64)
+        timings['matrix_pairs'] = int((npb * (npb - 1) // 2).sum())
+        # merge m of a problem with N records recomputes N - 2 - m distances
+        timings['ahc_pairs'] = int((nm * (npb - 2) - nm * (nm - 1) // 2).sum())
     if r['status'] == hipabi.SPKD_ENONFINITE:
         raise ValueError('array must not contain infs or NaNs')
     all_labels = hipabi.labels_from_merges_batch(seg_off, r['n_merges'], r['a'], r['b'])
