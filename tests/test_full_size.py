@@ -178,6 +178,35 @@ def test_batch_pipeline_equals_file_based_scripts(tmp_path, eng):
         e2.close()
 
 
+def test_chain_from_exp_files(tmp_path, eng):
+    """The three stages as the reference chains them (voice-detection2.py -> change
+    detection -> clustering): a `.exp` speech / non-speech token stream instead of a
+    ready-made VAD recipe, the HIP path against the C oracle on the same files."""
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    vd = pkg('voice_detection')
+    feats, vad, _ = synth.make_session(4711, 600, 4)
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    os.makedirs(os.path.join(tmp, 'exp'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'talk.fea'), feats)
+    toks = ['0 <w>'] + ['%d p %d <w>' % (a, b) for a, b in vad]
+    with open(os.path.join(tmp, 'exp', 'talk.exp'), 'w') as f:
+        f.write(' '.join(toks) + '\n')
+    with open(os.path.join(tmp, 'exp', 'talk.last_frame'), 'w') as f:
+        f.write(str(feats.shape[0]))
+    with open(os.path.join(tmp, 'wav.recipe'), 'w') as f:
+        f.write('audio=/data/talk.wav\n')
+    vd.main([os.path.join(tmp, 'wav.recipe'), os.path.join(tmp, 'exp'), '-o', os.path.join(tmp, 'vad.recipe')],
+            stdout=io.StringIO())
+    turns = open(os.path.join(tmp, 'vad.recipe')).read().splitlines()
+    assert len(turns) == len(vad) and turns[0].startswith('audio=/data/talk.wav lna=a_1 start-time=')
+    h = _run_scripts(tmp, eng, 'hip')
+    o = _run_scripts(tmp, COracleEngine(), 'orc')
+    assert h[0] == o[0] and h[1] == o[1]
+    assert h[1].count('speaker=') == h[0].count('\n')
+
+
 def test_empty_and_short_turns(eng):
     """Edge cases of dist_gw: a turn shorter than two windows gives only the tail
     line; an empty turn list is a no-op."""
