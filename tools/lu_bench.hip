@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "spkd_device.hpp"
-#include "spkd_quad.hpp"
+#include "quad_square.hpp"
 using namespace spkd;
 
 __global__ __launch_bounds__(256) void k_single(const double* __restrict__ M, double* __restrict__ out, int n, int reps) {

@@ -12,7 +12,7 @@
 // what hides the memory / LDS latency the one-wave form leaves exposed.
 //
 #pragma once
-#include "spkd_quad.hpp"
+#include "quad_square.hpp"
 #ifdef SPKD_NO_SB
 #define SPKD_SB() ((void)0)
 #else
