@@ -1,15 +1,22 @@
-import cProfile, pstats, sys, io
-sys.argv=['bench.py','--steps','3','--warmup','1','--no-cpu-baseline']
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""cProfile of bench.py's host side (run on the GPU box): python tools/prof_host.py"""
+import cProfile
+import io
+import os
+import pstats
 import runpy
-pr=cProfile.Profile()
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+sys.path.insert(0, ROOT)
+pr = cProfile.Profile()
 pr.enable()
 try:
-    runpy.run_path('/root/repo/bench.py', run_name='__main__')
+    runpy.run_path(os.path.join(ROOT, 'bench.py'), run_name='__main__')
 except SystemExit:
     pass
 pr.disable()
-s=io.StringIO()
-ps=pstats.Stats(pr,stream=s).sort_stats('cumulative')
-ps.print_stats(45)
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
 print(s.getvalue()[:9000])
