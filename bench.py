@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic sessions (tiled to --files)')
     ap.add_argument('--seconds', type=float, default=3600.0)
     ap.add_argument('--speakers', type=int, default=4)
-    ap.add_argument('--cpu-sample-seconds', type=float, default=1800.0)
+    ap.add_argument('--cpu-sample-seconds', type=float, default=900.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ahc-path', type=int, default=0, help='0 auto, 1 one workgroup per file, 2 chained launches')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
@@ -109,9 +109,11 @@ def main():
         feats, vad, _ = synth.make_session(1000003 * (rank + 1) + i, args.seconds, args.speakers)
         sessions.append((feats, [(s / 125.0, e / 125.0) for (s, e) in vad]))
     T = sessions[0][0].shape[0]
-    host = np.concatenate([sessions[i % len(sessions)][0] for i in range(args.files)])
-    frames = torch.from_numpy(host).to(dev)
-    del host
+    # the distinct sessions go up once and are tiled on the device (an 18 GB host copy
+    # per rank would be 144 GB on an 8-GPU node)
+    dev_sessions = [torch.from_numpy(s[0]).to(dev) for s in sessions]
+    frames = torch.cat([dev_sessions[i % len(sessions)] for i in range(args.files)])
+    del dev_sessions
     files = []
     for i in range(args.files):
         vad = sessions[i % len(sessions)][1]
