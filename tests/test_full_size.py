@@ -207,6 +207,28 @@ def test_chain_from_exp_files(tmp_path, eng):
     assert h[1].count('speaker=') == h[0].count('\n')
 
 
+def test_der_against_the_synthetic_ground_truth(tmp_path, eng):
+    """Accuracy sanity of the whole path with the reference's own scorer
+    (clus-performance.py, ported in exporters.py): the synthetic sessions come with the
+    true speaker of every frame.  The C oracle gives 0.87 % on this session."""
+    synth = pkg('synth')
+    ex = pkg('exporters')
+    feats, vad, truth = synth.make_session(4711, 600, 4)
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'x.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(synth.vad_recipe_text('x.wav', vad))
+    _, final, _, _ = _run_scripts(tmp, eng, 'hip')
+    rows = re.findall(r'start-time=(\S+) end-time=(\S+) speaker=(\S+)', final)
+    proposed = sorted((float(a), float(b), c) for a, b, c in rows)
+    baseline = [(a / 125.0, b / 125.0, 'true_%d' % k) for a, b, k in truth]
+    correct, incorrect = ex.der(baseline, proposed)
+    rate = incorrect / float(correct + incorrect)
+    print('DER vs ground truth: %.4f' % rate)
+    assert rate < 0.02
+
+
 def test_empty_and_short_turns(eng):
     """Edge cases of dist_gw: a turn shorter than two windows gives only the tail
     line; an empty turn list is a no-op."""
