@@ -218,6 +218,10 @@ __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (
 constexpr int GW_WAVES = 4;
 constexpr int GW_TPB = GW_WAVES * WAVE;
 constexpr int ERR_SWEEP = 16;                                // internal: a wanted position behind the sweep
+// pointer to global memory in a non-kernel function: a plain pointer there is generic,
+// its loads and stores are flat_* and count in lgkmcnt too, so every LDS wait of the
+// accumulation would also wait for the tile prefetch and the record dumps in flight
+#define SPKD_GLOBAL __attribute__((address_space(1)))
 constexpr int SW_BLOCKS = 210;
 constexpr int GW_TILE = 128;                                 // frames per LDS tile (float [128][40])
 
@@ -236,7 +240,8 @@ __device__ __forceinline__ SweepLane sweep_lane(int tid) {
     return s;
 }
 
-__device__ __forceinline__ void sweep_dump(double* rec, const SweepLane& SL, const double (&acc)[4]) {
+template <class Ptr>
+__device__ __forceinline__ void sweep_dump(Ptr rec, const SweepLane& SL, const double (&acc)[4]) {
     if (!SL.on) return;
     const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
     rec[tri_slot(r0, j0)] = acc[0];
@@ -245,7 +250,7 @@ __device__ __forceinline__ void sweep_dump(double* rec, const SweepLane& SL, con
     rec[tri_slot(r0 + 1, j0 + 1)] = acc[3];
 }
 
-__device__ __forceinline__ void sweep_gather(const double* __restrict__ rec, const SweepLane& SL, double (&acc)[4]) {
+__device__ __forceinline__ void sweep_gather(const SPKD_GLOBAL double* rec, const SweepLane& SL, double (&acc)[4]) {
     const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
     acc[0] = rec[tri_slot(r0, j0)];
     acc[1] = (SL.bi > SL.bj) ? rec[tri_slot(r0, j0 + 1)] : 0.0;
@@ -270,11 +275,11 @@ constexpr int GW_STAGE = (GW_TILE * D + GW_TPB - 1) / GW_TPB;     // floats per 
 // (branch-free: out-of-range slots re-read element 0; `t` is the caller's opaque copy
 // of the thread index, so that none of this address arithmetic is hoisted out of the
 // scan loop and kept alive -- i.e. spilled -- across the elimination code)
-__device__ __forceinline__ void sweep_issue(const float* __restrict__ fr, long long pos, long long limit,
+__device__ __forceinline__ void sweep_issue(const SPKD_GLOBAL float* fr, long long pos, long long limit,
                                             int t, float (&st)[GW_STAGE]) {
     const long long left = limit - pos;
     const int tl = (int)(left < GW_TILE ? (left < 0 ? 0 : left) : GW_TILE);
-    const float* src = fr + pos * D;
+    const SPKD_GLOBAL float* src = fr + pos * D;
     const int nfl = tl * D;
 #pragma unroll
     for (int u = 0; u < GW_STAGE; ++u) {
@@ -284,7 +289,7 @@ __device__ __forceinline__ void sweep_issue(const float* __restrict__ fr, long l
 }
 
 template <class OnReach>
-__device__ __forceinline__ void gw_sweep(const float* __restrict__ fr, float* xs, const SweepLane& SL,
+__device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs, const SweepLane& SL,
                                          int tid, double (&acc)[4], long long pos, long long want,
                                          long long limit, OnReach on_reach, int* err) {
 #ifdef SPKD_PROFILE
@@ -374,13 +379,15 @@ __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, d
     float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
     const int tid = threadIdx.x;
     const SweepLane SL = sweep_lane(tid);
+    const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
+    SPKD_GLOBAL double* gcache = (SPKD_GLOBAL double*)cache;
     double acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = persist[e * GW_TPB + tid];
     const long long want = built_k < C ? (long long)(start + built_i) : c;
-    gw_sweep(fr, xs, SL, tid, acc, sweep_pos, want, c, [&](long long pos) -> long long {
+    gw_sweep(gfr, xs, SL, tid, acc, sweep_pos, want, c, [&](long long pos) -> long long {
         if (built_k < C) {
-            sweep_dump(cache + built_k * TREC, SL, acc);
+            sweep_dump(gcache + built_k * TREC, SL, acc);
             ++built_k;
             built_i += istep;
             if (built_k == C) {             // the sweep rests here until the window grows
@@ -410,13 +417,15 @@ __device__ __noinline__ void gw_sweep_fine(const float* __restrict__ fr, double*
     float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
     const int tid = threadIdx.x;
     const SweepLane SL = sweep_lane(tid);
+    const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
+    SPKD_GLOBAL double* gcache = (SPKD_GLOBAL double*)cache;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (base) sweep_gather(base, SL, acc);
+    if (base) sweep_gather((const SPKD_GLOBAL double*)base, SL, acc);
     double fx = fine_i0;
     long long fk = 0;
     const long long last = (long long)(start + (fine_i0 + (double)(F - 1)));
-    gw_sweep(fr, xs, SL, tid, acc, base_pos, (long long)(start + fx), last, [&](long long) -> long long {
-        sweep_dump(cache + (first_slot + fk) * TREC, SL, acc);
+    gw_sweep(gfr, xs, SL, tid, acc, base_pos, (long long)(start + fx), last, [&](long long) -> long long {
+        sweep_dump(gcache + (first_slot + fk) * TREC, SL, acc);
         ++fk;
         fx += 1;
         return fk < F ? (long long)(start + fx) : -1;
@@ -562,6 +571,26 @@ constexpr int GW_LDS_BYTES = TREC * 8 + 4 * GW_TPB * 8 + GW_TILE * DA * 4;
 #define GW_TICK(i) ((void)0)
 #endif
 
+// The decision chain's scalar state lives in LDS, written by thread 0 and re-read by
+// everybody after a barrier.  As ordinary per-thread variables these twenty values are
+// live across the elimination code, get spilled, and every reload (a scratch load)
+// stalls on vmcnt behind whatever global stores are in flight: 27 k cycles per scan of
+// pure waiting in the phase clocks.  LDS reads are counted in lgkmcnt and cost ~100.
+struct GwState {
+    double start, end, ws, dws, cur_i, built_i, maxd, maxi, fine_i0;
+    long long n_memo;      // coarse candidates [0, n_memo) have their left term memoised
+    long long n_written;   // c_i[0 .. n_written) hold the coarse i sequence
+    long long C;           // coarse candidates of the current scan
+    // the sweep of this epoch: cache records [0, built_k) exist, the persistent sums stand
+    // at frame sweep_pos; built_i = i value of candidate built_k (the same repeated
+    // addition as cur_i, so the same doubles)
+    long long built_k, sweep_pos;
+    long long best_k, F, base, count;
+    int nw, nd;
+    int fine;              // kind of the scan about to run
+    int go;                // the outer loop continues
+};
+
 __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ cache_all, double* __restrict__ cand_all,
@@ -574,6 +603,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     double* persist = gw_lds + TREC;                 // [4][GW_TPB]: the sweep's sums at sweep_pos
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
+    __shared__ GwState S;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
     const TurnDesc T = turns[blockIdx.x];
@@ -599,74 +629,101 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 
     const int kind = P.kind;
     const double winsize = P.winsize, winstep = P.winstep, rate = P.rate;
-    double start = 0.0;
-    double end = start + winsize * 2;
     const double minfeas = rate / 2;
     const double istep = rate / 10;
-    double ws = minfeas;
-    double dws = P.deltaws;
-    long long n_memo = 0;            // coarse candidates [0, n_memo) have their left term memoised
-    long long n_written = 0;         // c_i[0 .. n_written) hold the coarse i sequence
-    long long C = 0;                 // coarse candidates of the current scan
-    double cur_i = minfeas;          // next i of the coarse sequence for this epoch
-    // the sweep of this epoch: cache records [0, built_k) exist, the persistent sums
-    // stand at frame sweep_pos; built_i = i value of candidate built_k (same repeated
-    // addition as cur_i, so the same doubles)
-    long long built_k = 0, sweep_pos = 0;
-    double built_i = minfeas;
-    long long best_k = 0;
-    int nw = 0, nd = 0;
     const double fn = (double)n;
     const double pen_w = P.lambdac * 0.5 * PEN_UNIT;
-    bool fine = false;               // kind of the scan about to run
-    double maxd = 0.0, maxi = 0.0;   // running maximum (carried from the coarse into the fine scan)
-    double fine_i0 = 0.0;
-    long long F = 0;
+    if (tid == 0) {
+        S.start = 0.0;
+        S.end = winsize * 2;
+        S.ws = minfeas;
+        S.dws = P.deltaws;
+        S.cur_i = minfeas;
+        S.built_i = minfeas;
+        S.maxd = 0.0; S.maxi = 0.0; S.fine_i0 = 0.0;
+        S.n_memo = 0; S.n_written = 0; S.C = 0;
+        S.built_k = 0; S.sweep_pos = 0;
+        S.best_k = 0; S.F = 0; S.base = 0; S.count = 0;
+        S.nw = 0; S.nd = 0; S.fine = 0;
+        S.go = (S.end <= fn) ? 1 : 0;
+    }
     __syncthreads();
     GW_TICK(0);
 
-    while (fine || end <= fn) {
-        long long base, count;
-        const long long a = (long long)start, c = (long long)end;
-        if (!fine) {
-            if (nw >= T.ev_cap) { if (tid == 0) atomicOr(err, 4); break; }
-            const double lim = end - start - minfeas;
-            while (cur_i < lim) {
-                if (C >= cap) break;
-                if (C >= n_written) { if (tid == 0) c_i[C] = cur_i; n_written = C + 1; }
-                ++C;
-                cur_i += istep;
+    while (S.go) {
+        // ---- (A) thread 0: the scan's candidate list (coarse: the i sequence grows with
+        // the window, CD:204-206; fine: single-frame steps around the maximum, CD:235-239)
+        if (tid == 0) {
+            if (!S.fine) {
+                if (S.nw >= T.ev_cap) {
+                    atomicOr(err, 4);
+                    S.go = 0;
+                } else {
+                    const double lim = S.end - S.start - minfeas;
+                    double cur_i = S.cur_i;
+                    long long C = S.C, n_written = S.n_written;
+                    while (cur_i < lim) {
+                        if (C >= cap) break;
+                        if (C >= n_written) { c_i[C] = cur_i; n_written = C + 1; }
+                        ++C;
+                        cur_i += istep;
+                    }
+                    S.cur_i = cur_i; S.C = C; S.n_written = n_written;
+                    S.base = 0;
+                    S.count = C;
+                }
+            } else {
+                const double fine_i0 = S.maxi - istep;
+                const double endtune = S.maxi + istep;
+                long long F = 0;
+                for (double x = fine_i0; x < endtune; x += 1) ++F;
+                S.fine_i0 = fine_i0;
+                S.F = F;
+                if (S.C + F > cap) {
+                    atomicOr(err, 4);
+                    S.go = 0;
+                } else {
+                    // the fine i sequence, by repeated +1 like the reference
+                    double x = fine_i0;
+                    for (long long k = 0; k < F; ++k) { c_i[S.C + k] = x; x += 1; }
+                    S.base = S.C;            // fine-scan scratch sits behind the coarse slots
+                    S.count = F;
+                }
             }
-            base = 0;
-            count = C;
-            // ---- extend the sweep: P(b_k) for the new candidates, then P(c)
-            {
-                const SweepOut so = gw_sweep_coarse(fr, cache, start, istep, built_i, built_k, C, sweep_pos, c, err);
-                if (built_k < C) { sweep_pos = so.pos; built_i = so.next_i; built_k = C; }
-            }
-        } else {
-            fine_i0 = maxi - istep;
-            const double endtune = maxi + istep;
-            F = 0;
-            for (double x = fine_i0; x < endtune; x += 1) ++F;
-            if (C + F > cap) { if (tid == 0) atomicOr(err, 4); break; }
-            // the fine i sequence, by repeated +1 like the reference
-            if (tid == 0) {
-                double x = fine_i0;
-                for (long long k = 0; k < F; ++k) { c_i[C + k] = x; x += 1; }
-            }
-            base = C;                // fine-scan scratch sits behind the coarse slots
-            count = F;
-            // ---- P at the F single-frame positions: start from a coarse candidate two
-            // steps below the maximum (always at or below the first fine position)
-            if (best_k >= 2)
-                gw_sweep_fine(fr, cache, cache + (best_k - 2) * TREC, (long long)(start + c_i[best_k - 2]),
-                              start, fine_i0, F, C, err);
-            else
-                gw_sweep_fine(fr, cache, nullptr, a, start, fine_i0, F, C, err);
         }
         __syncthreads();
+        if (!S.go) break;
+        // ---- (B) the sweep: P(b_k) for the new candidates, then P(c); fine: P at the F
+        // single-frame positions, from a coarse candidate two steps below the maximum
+        // (always at or below the first fine position)
+        {
+            const double start = S.start;
+            const long long a = (long long)start, c = (long long)S.end;
+            SweepOut so;
+            so.pos = 0; so.next_i = 0.0;
+            const long long C = S.C, built_k = S.built_k;
+            const bool coarse = !S.fine;
+            if (coarse) {
+                so = gw_sweep_coarse(fr, cache, start, istep, S.built_i, built_k, C, S.sweep_pos, c, err);
+            } else {
+                const long long best_k = S.best_k;
+                if (best_k >= 2)
+                    gw_sweep_fine(fr, cache, cache + (best_k - 2) * TREC, (long long)(start + c_i[best_k - 2]),
+                                  start, S.fine_i0, S.F, C, err);
+                else
+                    gw_sweep_fine(fr, cache, nullptr, a, start, S.fine_i0, S.F, C, err);
+            }
+            __syncthreads();             // everybody has read its arguments; the records are visible
+            if (tid == 0 && coarse && built_k < C) { S.sweep_pos = so.pos; S.built_i = so.next_i; S.built_k = C; }
+        }
         GW_TICK(1);
+        // ---- (C) the scan's matrices
+        const bool fine = S.fine != 0;
+        const double start = S.start;
+        const long long a = (long long)start, c = (long long)S.end;
+        const long long base = S.base, count = S.count;
+        {
+        const long long n_memo = S.n_memo;
         const double N = (double)(c - a);
         const bool pooled = (kind == SPKD_BIC && !fine);
         if (kind == SPKD_KL2) {
@@ -728,12 +785,14 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 }
             }
         }
+        }
         __syncthreads();
         GW_TICK(2);
 #ifdef SPKD_PROFILE
         ++prof_scans;
 #endif
-        // ---- finish the distances.  GLR: -(N/2) ((N1/N) log|S1| + (N2/N) log|S2| - log|W|)
+        const double N = (double)(c - a);
+        // ---- (D) finish the distances.  GLR: -(N/2) ((N1/N) log|S1| + (N2/N) log|S2| - log|W|)
         if (kind == SPKD_GLR) {
             for (long long k = tid; k < count; k += GW_TPB) {
                 const long long slot = base + k;
@@ -758,78 +817,95 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             }
             __syncthreads();
         }
-        for (long long k = tid; k < count; k += GW_TPB) {
-            const long long slot = base + k;
-            const double d = c_x[slot];
-            if ((P.trace && !fine) || fabs(d) == __builtin_huge_val()) {
-                const long long b = (long long)(start + c_i[slot]);
-                const long long w = fine ? (long long)(nw - 1) : (long long)nw;
-                log_cand(clog, log_cap, log_count, turn, fine ? 0 : 1,
-                         (w << 32) | (fine ? 0x80000000LL : 0LL) | k, start, c_i[slot], d, b - a, c - b);
+        {
+            const int nw = S.nw;
+            for (long long k = tid; k < count; k += GW_TPB) {
+                const long long slot = base + k;
+                const double d = c_x[slot];
+                if ((P.trace && !fine) || fabs(d) == __builtin_huge_val()) {
+                    const long long b = (long long)(start + c_i[slot]);
+                    const long long w = fine ? (long long)(nw - 1) : (long long)nw;
+                    log_cand(clog, log_cap, log_count, turn, fine ? 0 : 1,
+                             (w << 32) | (fine ? 0x80000000LL : 0LL) | k, start, c_i[slot], d, b - a, c - b);
+                }
             }
         }
         GW_TICK(3);
+        // ---- (E) arg-max (all threads), then thread 0 takes the decision (CD:222-284)
         if (!fine) {
-            if (C > n_memo) n_memo = C;
-            BestD best = block_argmax<GW_WAVES>(c_x, C, NEG_MAXINT_M1, red);
-            const bool found = best.k >= 0;
-            maxd = best.d;
-            maxi = found ? c_i[best.k] : 0.0;
-            best_k = found ? best.k : 0;
+            const long long C = count;
+            const BestD best = block_argmax<GW_WAVES>(c_x, C, NEG_MAXINT_M1, red);
             if (tid == 0) {
+                if (C > S.n_memo) S.n_memo = C;
+                const bool found = best.k >= 0;
+                const double maxd = best.d;
+                const int nw = S.nw;
+                S.maxd = maxd;
+                S.maxi = found ? c_i[best.k] : 0.0;
+                S.best_k = found ? best.k : 0;
                 win_maxd[T.ev_off + nw] = found ? maxd : __builtin_nan("");
                 win_det[T.ev_off + nw] = 0;
-            }
-            ++nw;
-            if (found && maxd > P.threshold) {
-                fine = true;             // next scan: fine tune around maxi (CD:231-251)
-                continue;
-            }
-            // negative: enlarge the window (CD:271-284)
-            if (end + ws <= fn) {
-                end += ws;
-                if (ws < winstep) { ws += dws; dws *= 2; }
-                if (ws > winstep) ws = winstep;
-            } else if (end != fn) {
-                end = fn;
-            } else {
-                break;
+                S.nw = nw + 1;
+                if (found && maxd > P.threshold) {
+                    S.fine = 1;              // next scan: fine tune around maxi (CD:231-251)
+                } else {
+                    // negative: enlarge the window (CD:271-284)
+                    double end = S.end, ws = S.ws, dws = S.dws;
+                    if (end + ws <= fn) {
+                        end += ws;
+                        if (ws < winstep) { ws += dws; dws *= 2; }
+                        if (ws > winstep) ws = winstep;
+                        S.go = (end <= fn) ? 1 : 0;
+                    } else if (end != fn) {
+                        end = fn;
+                        S.go = 1;
+                    } else {
+                        S.go = 0;
+                    }
+                    S.end = end; S.ws = ws; S.dws = dws;
+                }
             }
         } else {
-            BestD fb = block_argmax<GW_WAVES>(c_x + C, F, maxd, red);
-            if (fb.k >= 0) { maxd = fb.d; maxi = c_i[C + fb.k]; }
+            const long long C = S.C, F = count;
+            const BestD fb = block_argmax<GW_WAVES>(c_x + C, F, S.maxd, red);
             if (tid == 0) {
+                double maxd = S.maxd, maxi = S.maxi;
+                if (fb.k >= 0) { maxd = fb.d; maxi = c_i[C + fb.k]; }
+                const int nd = S.nd;
                 det_start[T.ev_off + nd] = start;
                 det_maxi[T.ev_off + nd] = maxi;
                 det_d[T.ev_off + nd] = maxd;
-                win_det[T.ev_off + nw - 1] = 1;
+                win_det[T.ev_off + S.nw - 1] = 1;
+                S.nd = nd + 1;
+                S.maxd = maxd; S.maxi = maxi;
+                S.fine = 0;
+                S.n_memo = 0;
+                S.n_written = S.n_written < C ? S.n_written : C;   // fine-scan scratch overwrote slots >= C
+                S.C = 0;
+                S.cur_i = minfeas;
+                const double nstart = start + maxi;
+                S.start = nstart;
+                // new epoch: the sweep restarts at the new window start
+                S.built_k = 0;
+                S.built_i = minfeas;
+                S.sweep_pos = (long long)nstart;
+                if (nstart + winsize * 2 <= fn) {
+                    S.end = nstart + winsize * 2;
+                    S.ws = minfeas;
+                    S.dws = P.deltaws;
+                    S.go = 1;
+                } else {
+                    S.go = 0;
+                }
             }
-            ++nd;
-            __syncthreads();             // reads of the scratch slots are done
-            fine = false;
-            n_memo = 0;
-            n_written = n_written < C ? n_written : C;   // fine-scan scratch overwrote slots >= C
-            C = 0;
-            cur_i = minfeas;
-            start += maxi;
-            // new epoch: the sweep restarts at the new window start
-            built_k = 0;
-            built_i = minfeas;
-            sweep_pos = (long long)start;
 #pragma unroll
             for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
-            if (start + winsize * 2 <= fn) {
-                end = start + winsize * 2;
-                ws = minfeas;
-                dws = P.deltaws;
-            } else {
-                break;
-            }
         }
+        __syncthreads();
     }
     if (tid == 0) {
-        n_win[turn] = nw;
-        final_start[turn] = start;
+        n_win[turn] = S.nw;
+        final_start[turn] = S.start;
     }
 #ifdef SPKD_PROFILE
     GW_TICK(1);
