@@ -10,6 +10,8 @@
 //                    spk-clustering2.py:185-222), one workgroup per problem,
 //                    device resident: arg-min with numpy semantics, statistics
 //                    merge, row recompute, v1 / v2 matrix update rules.
+//   k_ahc_update / k_ahc_select / k_ahc_pairs / k_ahc_final : the same loop as a chain
+//                    of chip-wide launches, for calls with few (long) problems.
 //
 // Per evaluated pair the algorithmic traffic is two records in, one double out
 // = 13 128 B; one factorisation per pair (the union), because
