@@ -32,9 +32,14 @@ class BatchFile(object):
         self.vad = [(float(s), float(e)) for (s, e) in vad]
 
 
-def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, timings=None):
+def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, timings=None,
+                        text_contract=True):
     """Returns, per file, the list of (start_s, end_s) the change-detection recipe
-    would contain (already passed through the 12-digit text round trip)."""
+    would contain (already passed through the 12-digit text round trip).
+    text_contract=False is the opt-in fused mode of SURVEY.md §8(f) row 4: the times go
+    to the clustering stage as the doubles they are, without being printed and re-read
+    (A-2) -- NOT the reference's semantics: a boundary within 1e-12 relative of a frame
+    edge can land one frame away."""
     rate = float(rate)
     _t0 = time.perf_counter()
     nturn = [len(f.vad) for f in files]
@@ -84,7 +89,9 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     t1[~is_tail] = d_end / rate + ls[det_turn]
     t0[is_tail] = r['final_start'] / rate + ls
     t1[is_tail] = ((le - ls) * rate) / rate + ls
-    rt = hipabi.py2_roundtrip(np.stack([t0, t1], axis=1).ravel()).reshape(-1, 2)
+    rt = np.stack([t0, t1], axis=1)
+    if text_contract:
+        rt = hipabi.py2_roundtrip(rt.ravel()).reshape(-1, 2)
     line_file = owner[line_turn]
     bounds = np.searchsorted(line_file, np.arange(len(files) + 1))
     out = [rt[bounds[i]:bounds[i + 1]] for i in range(len(files))]
@@ -155,10 +162,11 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
     return out
 
 
-def diarize_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, cl=DIA2_CL, timings=None):
+def diarize_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, cl=DIA2_CL, timings=None,
+                  text_contract=True):
     """CD (gw/BIC) + CL (hi/BIC) for a batch; returns per file an array of rows
     [start_s, end_s, speaker] in recipe order."""
-    segs = change_detect_batch(ctx, d_frames, total_frames, files, rate, cd, timings)
+    segs = change_detect_batch(ctx, d_frames, total_frames, files, rate, cd, timings, text_contract)
     res = cluster_batch(ctx, d_frames, total_frames, files, segs, rate, cl, timings)
     # recipe order of spk_cluster_hi's output: per file, sorted by (start*rate, end*rate, line)
     cnt = [len(s) for s in segs]

@@ -162,6 +162,12 @@ def test_batch_pipeline_equals_file_based_scripts(tmp_path, eng):
         files.append(pipeline.BatchFile(off, feats.shape[0], v))
         off += feats.shape[0]
     got = pipeline.diarize_batch(eng.ctx, eng.d_frames, frames.shape[0], files)
+    # the opt-in fused mode (no 12-digit text between the stages): same segmentation and
+    # labels here, times equal to 12 digits
+    fused = pipeline.diarize_batch(eng.ctx, eng.d_frames, frames.shape[0], files, text_contract=False)
+    for g, f in zip(got, fused):
+        assert g.shape == f.shape and np.array_equal(g[:, 2], f[:, 2])
+        assert np.allclose(g[:, :2], f[:, :2], rtol=1e-11, atol=0.0)
     e2 = pkg('engine').HipEngine(0)
     try:
         for k, (feats, vad, _) in enumerate(sessions):
