@@ -109,6 +109,16 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
     them.  Returns per file (labels[int array, 1-based, per segment in input
     order], merges[(a, b, d)])."""
     rate = float(rate)
+    # files without any segment are not clustering problems (spkd_ahc rejects empty ones)
+    if any(len(sg) == 0 for sg in segments):
+        keep = [i for i, sg in enumerate(segments) if len(sg) > 0]
+        out = [(np.zeros(0, dtype=np.int32), [] if want_merges else None) for _ in files]
+        if keep:
+            sub = cluster_batch(ctx, d_frames, total_frames, [files[i] for i in keep],
+                                [segments[i] for i in keep], rate, cl, timings, want_merges)
+            for i, r in zip(keep, sub):
+                out[i] = r
+        return out
     _t0 = time.perf_counter()
     cnt = [len(s) for s in segments]
     seg_off = np.zeros(len(files) + 1, dtype=np.int64)

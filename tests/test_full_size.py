@@ -184,6 +184,28 @@ def test_batch_pipeline_equals_file_based_scripts(tmp_path, eng):
         e2.close()
 
 
+def test_batch_with_empty_and_tiny_files(eng):
+    """Ragged batches: a file without any VAD turn, a file whose only turn is shorter than
+    two windows (one segment, one speaker) and a normal file, in one launch each stage."""
+    synth = pkg('synth')
+    pipeline = pkg('pipeline')
+    recipe = pkg('recipe')
+    feats, vad, _ = synth.make_session(77, 120, 3)
+    T = feats.shape[0]
+    frames = np.concatenate([feats, feats[:3000], feats])
+    eng.set_features(frames)
+    v = [(float(recipe.py2_float_str(a / 125.0)), float(recipe.py2_float_str(b / 125.0))) for a, b in vad]
+    files = [pipeline.BatchFile(0, T, []),                        # no speech at all
+             pipeline.BatchFile(T, 3000, [(2.0, 3.5)]),           # 187 frames: no scan fits
+             pipeline.BatchFile(T + 3000, T, v)]
+    got = pipeline.diarize_batch(eng.ctx, eng.d_frames, frames.shape[0], files)
+    assert got[0].shape == (0, 3)
+    assert got[1].tolist() == [[2.0, 3.5, 1.0]]
+    alone = pipeline.diarize_batch(eng.ctx, eng.d_frames, frames.shape[0], [files[2]])
+    assert np.array_equal(got[2], alone[0]) and len(got[2]) >= len(v)
+    assert pipeline.diarize_batch(eng.ctx, eng.d_frames, frames.shape[0], [files[0]])[0].shape == (0, 3)
+
+
 def test_chain_from_exp_files(tmp_path, eng):
     """The three stages as the reference chains them (voice-detection2.py -> change
     detection -> clustering): a `.exp` speech / non-speech token stream instead of a
