@@ -184,7 +184,7 @@ def main():
         # calibrated on k_chunk_stats, whose read volume is known exactly) -- only valid
         # for the workload those passes were taken on
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01d_bench256_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r01e_bench256_hbm_traffic.json')
         if (args.files, args.seconds, args.speakers) == (256, 3600.0, 4) and os.path.exists(tfile):
             with open(tfile) as f:
                 tk = json.load(f)['kernels'].get(dom)
