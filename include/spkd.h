@@ -143,6 +143,8 @@ typedef struct {         /* one logged candidate evaluation */
  *   h_final_start[t]     `start` when the loop ended (the tail line starts here)
  * h_log may be NULL (log_cap 0); *h_log_count receives the number of records the
  * run wanted to write (SPKD_EOVERFLOW if > log_cap).
+ * Device scratch held by the context: one 10 368-byte record of running moment sums
+ * per candidate slot, about turn_len / (rate / 10) slots per turn (0.83 KB per frame).
  */
 int64_t spkd_gw_event_capacity(int64_t turn_len, double rate);
 spkd_status spkd_gw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
