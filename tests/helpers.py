@@ -27,8 +27,13 @@ def session(meta):
 
 
 def load_cases():
-    with open(os.path.join(ROOT, 'tests', 'golden', 'cli_cases.json')) as f:
-        return json.load(f)['cases']
+    """Reference command lines: the DIA2-flag set plus the non-default growing-window
+    parameters (make_golden.py / make_golden_params.py)."""
+    cases = []
+    for name in ('cli_cases.json', 'cli_cases_params.json'):
+        with open(os.path.join(ROOT, 'tests', 'golden', name)) as f:
+            cases += json.load(f)['cases']
+    return cases
 
 
 def run_case(case, tmp, engine):
