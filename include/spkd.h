@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPKD_ABI_VERSION 1
+#define SPKD_ABI_VERSION 2
 #define SPKD_DIM 39
 #define SPKD_REC 820
 
@@ -51,9 +51,15 @@ typedef struct spkd_ctx spkd_ctx;
 
 int spkd_abi_version(void);
 
-/* device = HIP device ordinal; stream = a hipStream_t to launch on (e.g. the
- * caller's torch stream) or NULL for a stream owned by the context. */
+/* device = HIP device ordinal; stream = a hipStream_t to launch on, or NULL for a
+ * stream owned by the context.  The owned stream is a blocking one: it is ordered
+ * with work on the legacy default stream (handle 0, which is also what torch's
+ * default stream is), not with other non-blocking streams.
+ * spkd_create_on_stream always launches on the given handle, NULL included (NULL =
+ * the legacy default stream): this is the call for "the caller's current torch
+ * stream", whose handle is 0 unless the caller made a stream of its own. */
 spkd_status spkd_create(int device, void *stream, spkd_ctx **out);
+spkd_status spkd_create_on_stream(int device, void *stream, spkd_ctx **out);
 void spkd_destroy(spkd_ctx *ctx);
 const char *spkd_last_error(const spkd_ctx *ctx);
 spkd_status spkd_sync(spkd_ctx *ctx);
@@ -135,7 +141,8 @@ typedef struct {         /* one logged candidate evaluation */
 /* Growing-window detector, dist_gw (spk-change-detection.py:180-288), all turns
  * of one feature array in one launch, one workgroup per turn.
  * Per turn t the events land at [h_ev_off[t], h_ev_off[t+1]) of the h_win_ and
- * h_det_ arrays; capacity per turn must be >= spkd_gw_event_capacity(len, rate).
+ * h_det_ arrays; capacity per turn must be >= spkd_gw_event_capacity_p(len, params).
+ * winstep < 1 frame is rejected (the reference's loop does not terminate there).
  *   h_n_win[t]           number of coarse scans (outer iterations)
  *   h_win_maxd[...]      best coarse distance of each scan (NaN: none accepted)
  *   h_win_det[...]       1 if that scan ended in a detection
@@ -147,6 +154,10 @@ typedef struct {         /* one logged candidate evaluation */
  * per candidate slot, about turn_len / (rate / 10) slots per turn (0.83 KB per frame).
  */
 int64_t spkd_gw_event_capacity(int64_t turn_len, double rate);
+/* the bound for any window step (spkd_gw_event_capacity assumes winstep >= 0.2 * rate,
+ * i.e. -st >= 0.2 s; below that the window grows by winstep frames per negative scan
+ * and a turn needs up to turn_len / winstep scans); -1 for parameters spkd_gw rejects */
+int64_t spkd_gw_event_capacity_p(int64_t turn_len, const spkd_cd_params *params);
 spkd_status spkd_gw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
                     const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
                     const spkd_cd_params *params, const int64_t *h_ev_off,

@@ -104,7 +104,8 @@ class COracleEngine(object):
 
     def gw_raw(self, f0, f1, p, log_cap=1 << 16):
         n = f1 - f0
-        cap = int(n / (0.2 * p.rate)) + 8
+        # window-count bound for any window step (spkd_gw_event_capacity_p)
+        cap = int(n / min(0.2 * p.rate, max(p.winstep, 1.0))) + 8
         n_win = C.c_int32(0)
         win_maxd = np.zeros(cap); win_det = np.zeros(cap, dtype=np.int32)
         ds = np.zeros(cap); dm = np.zeros(cap); dd = np.zeros(cap)

@@ -27,6 +27,7 @@ struct spkd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool gw_lds_ok = false;
     std::string err;
     int* d_err = nullptr;
     unsigned long long* d_counter = nullptr;
@@ -129,7 +130,7 @@ extern "C" {
 
 int spkd_abi_version(void) { return SPKD_ABI_VERSION; }
 
-spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
+static spkd_status create_ctx(int device, void* stream, bool borrow, spkd_ctx** out) {
     if (!out) return SPKD_EINVAL;
     *out = nullptr;
     int count = 0;
@@ -137,10 +138,12 @@ spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
     spkd_ctx* c = new spkd_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete c; return SPKD_EHIP; }
-    if (stream) {
-        c->stream = (hipStream_t)stream;
+    if (borrow) {
+        c->stream = (hipStream_t)stream;           // NULL = the legacy default stream itself
     } else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SPKD_EHIP; }
+        // a BLOCKING stream: ordered after (and before) work on the legacy default stream,
+        // which is where torch's default stream puts the producers of d_frames
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) { delete c; return SPKD_EHIP; }
         c->own_stream = true;
     }
     if (hipMalloc(&c->d_err, sizeof(int)) != hipSuccess ||
@@ -154,11 +157,22 @@ spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
             spkd_destroy(c);
             return SPKD_EHIP;
         }
-    // kernels that need more than 64 KiB of dynamic LDS
-    // k_gw carves more than 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS_BYTES);
+    // k_gw carves its LDS dynamically: the size must fit the device and be admitted
+    // for the kernel, or every later launch fails -- checked once, reported by spkd_gw
+    int lds_max = 0;
+    c->gw_lds_ok = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess &&
+                   GW_LDS_BYTES <= lds_max &&
+                   hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS_BYTES) == hipSuccess;
     *out = c;
     return SPKD_OK;
+}
+
+spkd_status spkd_create(int device, void* stream, spkd_ctx** out) {
+    return create_ctx(device, stream, stream != nullptr, out);
+}
+
+spkd_status spkd_create_on_stream(int device, void* stream, spkd_ctx** out) {
+    return create_ctx(device, stream, true, out);
 }
 
 void spkd_destroy(spkd_ctx* c) {
@@ -491,7 +505,17 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
 int64_t spkd_gw_event_capacity(int64_t turn_len, double rate) {
     if (turn_len < 0 || !(rate >= 10.0)) return -1;
     // every outer iteration either advances start by >= 0.4*rate or grows end by >= 0.5*rate
+    // (true while winstep >= 0.2*rate; spkd_gw_event_capacity_p covers every winstep)
     return (int64_t)((double)turn_len / (0.2 * rate)) + 8;
+}
+
+int64_t spkd_gw_event_capacity_p(int64_t turn_len, const spkd_cd_params* P) {
+    if (turn_len < 0 || !P || !(P->rate >= 10.0) || !(P->winstep >= 1.0)) return -1;
+    // an outer iteration that detects advances `start` by maxi >= minfeas - istep = 0.4*rate;
+    // one that does not grows `end` by ws, and ws is clamped to winstep from the second
+    // growth of an epoch on (CD:273-284): at least min(0.5*rate, winstep) frames
+    const double step = std::min(0.2 * P->rate, std::min(0.5 * P->rate, P->winstep));
+    return (int64_t)((double)turn_len / step) + 8;
 }
 
 int64_t spkd_sw_window_count(int64_t turn_len, double winsize, double winstep) {
@@ -551,14 +575,16 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
         !h_det_maxi || !h_det_d || !h_final_start)
         return fail(c, SPKD_EINVAL, "null argument");
     if (P->kind < 0 || P->kind > 2) return fail(c, SPKD_EINVAL, "gw: bad kind");
-    if (!(P->rate >= 10.0) || !(P->winsize >= 1.0)) return fail(c, SPKD_EINVAL, "gw: rate >= 10 and winsize >= 1 frame required");
+    if (!(P->rate >= 10.0) || !(P->winsize >= 1.0) || !(P->winstep >= 1.0))
+        return fail(c, SPKD_EINVAL, "gw: rate >= 10, winsize >= 1 frame and winstep >= 1 frame required");
+    if (!c->gw_lds_ok) return fail(c, SPKD_EHIP, "gw: the kernel's dynamic LDS size was not admitted on this device");
     std::vector<TurnDesc> turns;
     int64_t n_snap, n_cand;
     spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_ev_off, true, turns, n_snap, n_cand);
     if (st != SPKD_OK) return st;
     for (int64_t t = 0; check_capacity && t < n_turns; ++t)
-        if (turns[(size_t)t].ev_cap < spkd_gw_event_capacity(turns[(size_t)t].len, P->rate))
-            return fail(c, SPKD_EINVAL, "gw: event capacity too small, see spkd_gw_event_capacity");
+        if (turns[(size_t)t].ev_cap < spkd_gw_event_capacity_p(turns[(size_t)t].len, P))
+            return fail(c, SPKD_EINVAL, "gw: event capacity too small, see spkd_gw_event_capacity_p");
     if ((st = begin_call(c)) != SPKD_OK) return st;
     const int64_t n_ev = h_ev_off[n_turns];
     TurnDesc* d_turns = nullptr;

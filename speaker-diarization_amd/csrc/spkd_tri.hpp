@@ -45,15 +45,23 @@ __device__ __forceinline__ double bcast16_nop(double v) {
     return r;
 }
 
-// column J of step K: a[i][J] += l_i * a[J][K].  Every column's first FMA waits
-// (its source a[J][K] was written one step earlier, possibly by the instruction just
-// before when few columns remain).
+// column J of step K: a[i][J] += l_i * a[J][K].  The DPP sources of step K are the
+// column-K registers, last written by the FIRST column of step K - 1; every FMA of step
+// K comes after the step's pivot broadcast statement (an s_nop 1 + a DPP move, in program
+// order because both are volatile), i.e. more than two wait states after that write, so
+// the column FMAs carry no s_nop of their own.  tools/check_dpp_hazard.py verifies the
+// rule on the disassembly of the built library (the compiler could in principle copy a
+// source register right in front of a statement).  -DSPKD_TRI_COLNOP=1 restores a wait
+// in front of every column (the round-1 form).
+#ifndef SPKD_TRI_COLNOP
+#define SPKD_TRI_COLNOP 0
+#endif
 template <int K, int J>
 struct TriCol {
     static __device__ __forceinline__ void run(QuadRows& q, const double (&l)[QS]) {
         if constexpr (J < D) {
             constexpr int SJ = J / QL, TJ = J % QL;
-            fmac_bcast16<TJ, true>(q.r[SJ][J], q.r[SJ][K], l[SJ]);
+            fmac_bcast16<TJ, SPKD_TRI_COLNOP != 0>(q.r[SJ][J], q.r[SJ][K], l[SJ]);
 #pragma unroll
             for (int s = SJ + 1; s < QS; ++s) fmac_bcast16<TJ, false>(q.r[s][J], q.r[SJ][K], l[s]);
             TriCol<K, J + 1>::run(q, l);

@@ -16,10 +16,10 @@ TIMERS = {n: i for i, n in enumerate(['call', 'chunk_stats', 'reduce_sets', 'pai
 REC = 820
 DIM = 39
 
-EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
+EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
            'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
-           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw', 'spkd_gw_ex',
+           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
            'spkd_labels_from_merges', 'spkd_labels_from_merges_batch']
 
@@ -67,6 +67,7 @@ def load_library(path=None):
     P = C.POINTER
     lib.spkd_abi_version.restype = C.c_int
     lib.spkd_create.argtypes = [C.c_int, vp, P(vp)]
+    lib.spkd_create_on_stream.argtypes = [C.c_int, vp, P(vp)]
     lib.spkd_destroy.argtypes = [vp]
     lib.spkd_destroy.restype = None
     lib.spkd_last_error.argtypes = [vp]
@@ -82,6 +83,8 @@ def load_library(path=None):
     lib.spkd_distance_matrix.argtypes = [vp, C.c_int, dbl, vp, i64, vp]
     lib.spkd_gw_event_capacity.argtypes = [i64, dbl]
     lib.spkd_gw_event_capacity.restype = i64
+    lib.spkd_gw_event_capacity_p.argtypes = [i64, P(CdParams)]
+    lib.spkd_gw_event_capacity_p.restype = i64
     lib.spkd_gw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp, vp, vp, vp, vp, vp, vp,
                             vp, i64, P(i64)]
     lib.spkd_gw_ex.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, C.c_int, vp, vp, vp, vp, vp, vp,
@@ -94,7 +97,7 @@ def load_library(path=None):
     lib.spkd_py2_roundtrip.restype = None
     lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
     lib.spkd_labels_from_merges_batch.argtypes = [i64, vp, vp, vp, vp, vp]
-    if lib.spkd_abi_version() != 1:
+    if lib.spkd_abi_version() != 2:
         raise ImportError('libspkd_hip.so ABI version mismatch')
     if path is None:
         _lib = lib
@@ -142,9 +145,15 @@ class Context(object):
     """One (device, stream) context; owns nothing but the library's scratch."""
 
     def __init__(self, device=0, stream=None):
+        """stream=None: the context owns a (blocking) stream.  stream=<handle>, 0 included:
+        launch on exactly that hipStream_t (0 = the legacy default stream, which is what
+        ``torch.cuda.current_stream().cuda_stream`` returns for torch's default stream)."""
         self.lib = load_library()
         h = C.c_void_p()
-        st = self.lib.spkd_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if stream is None:
+            st = self.lib.spkd_create(int(device), None, C.byref(h))
+        else:
+            st = self.lib.spkd_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
         if st != SPKD_OK:
             raise SpkdError(st, 'spkd_create failed (no usable HIP device %d?)' % device)
         self.h = h
@@ -244,10 +253,12 @@ class Context(object):
         b = np.ascontiguousarray(begins, dtype=np.int64)
         e = np.ascontiguousarray(ends, dtype=np.int64)
         nt = len(b)
-        if not params.rate >= 10.0:
-            raise SpkdError(SPKD_EINVAL, 'unsupported frame rate for the growing window (needs >= 10)')
-        # == spkd_gw_event_capacity(len, rate), vectorised
-        full = ((e - b).astype(np.float64) / (0.2 * params.rate)).astype(np.int64) + 8
+        if not (params.rate >= 10.0 and params.winstep >= 1.0):
+            raise SpkdError(SPKD_EINVAL, 'unsupported growing-window parameters (frame rate >= 10 and '
+                                         'a window step of at least one frame needed)')
+        # == spkd_gw_event_capacity_p(len, params), vectorised
+        step = min(0.2 * params.rate, 0.5 * params.rate, params.winstep)
+        full = ((e - b).astype(np.float64) / step).astype(np.int64) + 8
         while True:
             caps = (full // 4 + 8) if tight else full
             off = np.zeros(nt + 1, dtype=np.int64)

@@ -28,9 +28,10 @@ def session(meta):
 
 def load_cases():
     """Reference command lines: the DIA2-flag set plus the non-default growing-window
-    parameters (make_golden.py / make_golden_params.py)."""
+    parameters and the sub-half-second window steps (make_golden.py /
+    make_golden_params.py / make_golden_r02.py)."""
     cases = []
-    for name in ('cli_cases.json', 'cli_cases_params.json'):
+    for name in ('cli_cases.json', 'cli_cases_params.json', 'cli_cases_r02.json'):
         with open(os.path.join(ROOT, 'tests', 'golden', name)) as f:
             cases += json.load(f)['cases']
     return cases

@@ -72,3 +72,23 @@ def test_degenerate_inputs():
             if w is None:
                 continue
             assert (math.isnan(w) and math.isnan(got)) or got == w
+
+
+def test_two_window_bic_function_goldens():
+    """The sliding-window geometry with BIC: the reference command line crashes
+    (SURVEY.md A-6), its bic() function on the same windows is the oracle
+    (tests/golden/functions_sw.json).  Both CPU oracles must reproduce it."""
+    from oracle.c_engine import COracleEngine
+    with open(os.path.join(ROOT, 'tests', 'golden', 'functions_sw.json')) as f:
+        g = json.load(f)
+    feats, _, _ = session(g['session'])
+    engines = [ne.NumpyEngine(), COracleEngine()]
+    for e in engines:
+        e.set_features(feats)
+    for w in g['windows']:
+        want = np.array([float.fromhex(v) for v in w['bic']])
+        assert len(want) > 3
+        for e, tol in zip(engines, (0.0, 1e-9)):
+            got = e.sw([tuple(w['turn'])], 'BIC', w['lambda'], w['winsize'], w['winstep'])[0]
+            assert len(got) == len(want)
+            assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) <= tol
