@@ -7,11 +7,29 @@ synthetic 1 h / 4-speaker feature files resident in HBM.
 
 One process per GPU (torchrun sets RANK / LOCAL_RANK / WORLD_SIZE).  Files are
 independent, so ranks share nothing on the data path: each rank owns its own
-batch ("weak" scaling) and the only collective is the max-reduce of the timing.
-A step = one pass of CD + CL over the rank's whole batch.  Rank 0 prints ONE JSON
-line: value = audio hours processed by all ranks per second.
+batch ("weak" scaling) and the only collective is the gather of the finished
+recipes on rank 0 (+ the max-reduce of the timing).  A step = one pass of CD + CL
+over the rank's whole batch.  Rank 0 prints ONE JSON line: value = audio hours
+processed by all ranks per second.
+
+What the line carries besides the contract's keys:
+  roofline            the kernel with the largest share of the step: algorithmic bytes
+                      (SURVEY.md §8d) / its HIP-event duration on the launch stream;
+                      `traffic` only from a PMC profile of THIS build (the profile's
+                      kernel time must match the one measured now within 5 %), else null
+  kernels             the same for every hot kernel
+  hbm_copy_GBps       device-to-device copy rate measured in this run (the achievable
+                      HBM rate next to the 8 TB/s spec)
+  verified            the batch result was compared with the file-based drop-in scripts
+                      before timing, and every timed step reproduced the same digest
+  other_configs       latency of BASELINE.json configs 2, 3 and 5 as single-file calls
+  cpu_baseline        oracle/numpy_engine.py (np.cov + det per distance, like the
+                      reference) on a bounded sample, this box's host cores
+  cpu_baseline_stats  oracle/spkd_oracle.c (fp64 sufficient statistics, the algorithmic
+                      twin of the GPU path) on one thread and on all cores
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -28,6 +46,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_FRAME = 156          # 39 float32, each frame read once per stage
 BYTES_PER_PAIR = 13128         # two 6 560-B records in, one double out
 REC_BYTES = 6560
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_bench256_hbm_traffic.json')
+
+CD_ARGS = ['-m', 'gw', '-d', 'BIC', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0']
+CL_ARGS = ['-m', 'hi', '-l', '1.3']
 
 
 def parse():
@@ -36,22 +58,55 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--files', type=int, default=256, help='1 h files per GPU per step')
-    ap.add_argument('--distinct', type=int, default=4, help='distinct synthetic sessions (tiled to --files)')
+    ap.add_argument('--distinct', type=int, default=0,
+                    help='distinct synthetic sessions (0 = every file its own; fewer are tiled)')
     ap.add_argument('--seconds', type=float, default=3600.0)
     ap.add_argument('--speakers', type=int, default=4)
+    ap.add_argument('--two-pass', action='store_true',
+                    help='read the frames once per stage (k_chunk_stats) instead of the fused single read')
     ap.add_argument('--cpu-sample-seconds', type=float, default=900.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the other-config latencies and the copy rate')
     ap.add_argument('--ahc-path', type=int, default=0, help='0 auto, 1 one workgroup per file, 2 chained launches')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     ap.add_argument('--share-device', action='store_true',
                     help='rehearsal only: every rank uses GPU 0 (needs --backend gloo)')
+    ap.add_argument('--dump-rows', default='', help='rank 0 writes the gathered rows of the last step here (.npz)')
     return ap.parse_args()
+
+
+def cpu_info():
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def _write_session(tmp, synth, feats, vad):
+    os.makedirs(os.path.join(tmp, 'fea'), exist_ok=True)
+    synth.write_fea(os.path.join(tmp, 'fea', 's.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(synth.vad_recipe_text('s.wav', vad))
+
+
+def _run_scripts(tmp, cli, eng):
+    import io
+    cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), os.path.join(tmp, 'fea') + '/', '-o',
+                               os.path.join(tmp, 'spkc.recipe')] + CD_ARGS, engine=eng, stdout=io.StringIO())
+    cli.main_clustering([os.path.join(tmp, 'spkc.recipe'), os.path.join(tmp, 'fea') + '/', '-o',
+                         os.path.join(tmp, 'out.recipe')] + CL_ARGS, variant=1, engine=eng, stdout=io.StringIO())
+    return open(os.path.join(tmp, 'out.recipe')).read()
 
 
 def cpu_baseline(args, synth, cli):
     """The numpy oracle (np.cov + det per distance, like the reference) on a
     bounded sample of the same workload, on this box's host cores."""
-    import io
     import tempfile
     from oracle.numpy_engine import NumpyEngine
     try:
@@ -62,22 +117,45 @@ def cpu_baseline(args, synth, cli):
     secs = args.cpu_sample_seconds
     feats, vad, _ = synth.make_session(777, secs, args.speakers)
     with tempfile.TemporaryDirectory() as tmp:
-        os.makedirs(os.path.join(tmp, 'fea'))
-        synth.write_fea(os.path.join(tmp, 'fea', 's.fea'), feats)
-        with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
-            f.write(synth.vad_recipe_text('s.wav', vad))
-        eng = NumpyEngine()
+        _write_session(tmp, synth, feats, vad)
         t0 = time.perf_counter()
-        cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), os.path.join(tmp, 'fea') + '/', '-o',
-                                   os.path.join(tmp, 'spkc.recipe'), '-m', 'gw', '-d', 'BIC', '-w', '1.0',
-                                   '-st', '3.0', '-dws', '0.1', '-l', '1.0'], engine=eng, stdout=io.StringIO())
-        cli.main_clustering([os.path.join(tmp, 'spkc.recipe'), os.path.join(tmp, 'fea') + '/', '-o',
-                             os.path.join(tmp, 'out.recipe'), '-m', 'hi', '-l', '1.3'], variant=1,
-                            engine=eng, stdout=io.StringIO())
+        _run_scripts(tmp, cli, NumpyEngine())
         dt = time.perf_counter() - t0
+    model, ncpu = cpu_info()
     return {'value': (secs / 3600.0) / dt, 'unit': 'hours-audio/s', 'cores': int(cores), 'kind': 'port',
+            'cpu': model, 'host_cpus': ncpu,
             'sample': '%.0f s of the same synthetic %d-speaker audio, CD gw/BIC + CL hi/BIC through '
-                      'oracle/numpy_engine.py (np.cov + det per distance), %.1f s wall' % (secs, args.speakers, dt)}
+                      'oracle/numpy_engine.py (np.cov + det per distance; BLAS threads = cores), %.1f s wall'
+                      % (secs, args.speakers, dt)}
+
+
+def cpu_baseline_stats(args, synth, cli):
+    """The C restatement on sufficient statistics (the fair comparison for the GPU kernels:
+    most of the gap to the numpy path is algorithmic), one thread and all cores, on one
+    whole file of the benchmark's workload."""
+    import tempfile
+    from oracle.c_engine import COracleEngine
+    feats, vad, _ = synth.make_session(777, args.seconds, args.speakers)
+    out = {'unit': 'hours-audio/s', 'kind': 'port', 'cpu': cpu_info()[0],
+           'sample': 'one %.0f s %d-speaker file, CD gw/BIC + CL hi/BIC through oracle/spkd_oracle.c '
+                     '(turns and pair distances spread over OpenMP / host threads)' % (args.seconds, args.speakers)}
+    with tempfile.TemporaryDirectory() as tmp:
+        _write_session(tmp, synth, feats, vad)
+        for key, threads in (('one_thread', 1), ('all_cores', 0)):
+            eng = COracleEngine(threads)
+            t0 = time.perf_counter()
+            _run_scripts(tmp, cli, eng)
+            dt = time.perf_counter() - t0
+            out[key] = {'value': (args.seconds / 3600.0) / dt, 'threads': int(eng.threads), 'wall_s': round(dt, 2)}
+    return out
+
+
+def rows_digest(rows_by_file):
+    h = hashlib.sha256()
+    for i in sorted(rows_by_file):
+        h.update(np.int64(i).tobytes())
+        h.update(np.ascontiguousarray(rows_by_file[i], dtype=np.float64).tobytes())
+    return h.hexdigest()
 
 
 def main():
@@ -100,38 +178,44 @@ def main():
             dist.init_process_group(args.backend)
     hipabi = importlib.import_module(PKG + '.hipabi')
     synth = importlib.import_module(PKG + '.synth')
+    synth_device = importlib.import_module(PKG + '.synth_device')
     pipeline = importlib.import_module(PKG + '.pipeline')
     cli = importlib.import_module(PKG + '.cli')
-
-    # ---- synthetic batch, resident in HBM before the timed region
-    sessions = []
-    for i in range(max(1, min(args.distinct, args.files))):
-        feats, vad, _ = synth.make_session(1000003 * (rank + 1) + i, args.seconds, args.speakers)
-        sessions.append((feats, [(s / 125.0, e / 125.0) for (s, e) in vad]))
-    T = sessions[0][0].shape[0]
-    # the distinct sessions go up once and are tiled on the device (an 18 GB host copy
-    # per rank would be 144 GB on an 8-GPU node)
-    dev_sessions = [torch.from_numpy(s[0]).to(dev) for s in sessions]
-    frames = torch.cat([dev_sessions[i % len(sessions)] for i in range(args.files)])
-    del dev_sessions
-    files = []
-    for i in range(args.files):
-        vad = sessions[i % len(sessions)][1]
-        # times as the VAD recipe would state them (12 significant digits)
-        rec = importlib.import_module(PKG + '.recipe')
-        vad = [(float(rec.py2_float_str(s)), float(rec.py2_float_str(e))) for (s, e) in vad]
-        files.append(pipeline.BatchFile(i * T, T, vad))
-    total = args.files * T
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = hipabi.Context(local, stream)
-    ptr = frames.data_ptr()
-
+    rec = importlib.import_module(PKG + '.recipe')
     distributed = importlib.import_module(PKG + '.distributed')
+    engine_mod = importlib.import_module(PKG + '.engine')
+
+    # ---- synthetic batch, generated on the device (bit-identical to synth.make_session),
+    # resident in HBM before the timed region.  Seeds depend on the GLOBAL file index, so a
+    # file is the same whichever rank owns it.
+    n_distinct = args.files if args.distinct <= 0 else max(1, min(args.distinct, args.files))
+
+    def vad_times(vad):
+        # times as the VAD recipe would state them (12 significant digits)
+        return [(float(rec.py2_float_str(s / 125.0)), float(rec.py2_float_str(e / 125.0))) for (s, e) in vad]
+
+    sessions = []
+    for i in range(n_distinct):
+        gi = rank + world * i                        # global index of this rank's i-th file
+        feats, vad, _ = synth_device.make_session_device(1000003 + gi, args.seconds, args.speakers, device=dev)
+        sessions.append((feats, vad))
+    T = int(sessions[0][0].shape[0])
+    frames = torch.cat([sessions[i % n_distinct][0] for i in range(args.files)])
+    files = [pipeline.BatchFile(i * T, T, vad_times(sessions[i % n_distinct][1])) for i in range(args.files)]
+    first_host = (sessions[0][0].cpu().numpy(), sessions[0][1]) if rank == 0 else None
+    del sessions
+    total = args.files * T
+    torch.cuda.synchronize()
+    # the library launches on torch's current stream (handle 0 = the default stream)
+    ctx = hipabi.Context(local, torch.cuda.current_stream().cuda_stream)
+    ptr = frames.data_ptr()
+    fused = not args.two_pass
+    cl = dict(pipeline.DIA2_CL, path=args.ahc_path)
 
     def step(tm=None):
-        rows = pipeline.diarize_batch(ctx, ptr, total, files, cl=dict(pipeline.DIA2_CL, path=args.ahc_path), timings=tm)
+        rows = pipeline.diarize_batch(ctx, ptr, total, files, cl=cl, timings=tm, fused=fused)
         if world == 1:
-            return rows
+            return {i: r for i, r in enumerate(rows)}
         # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)
         return distributed.gather_rows([(rank + world * i, r) for i, r in enumerate(rows)], dist)
 
@@ -140,8 +224,28 @@ def main():
         if world > 1:
             dist.barrier()
 
-    out = None
-    for _ in range(args.warmup):
+    # ---- before timing: the batch result of this rank's first file == the file-based
+    # drop-in scripts on the same file (rank 0 only; the scripts re-read the .fea)
+    verified = None
+    out = step()
+    if rank == 0:
+        import re
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            _write_session(tmp, synth, first_host[0], first_host[1])
+            eng = engine_mod.HipEngine(local)
+            try:
+                final = _run_scripts(tmp, cli, eng)
+            finally:
+                eng.close()
+        want = [(float(a), float(b), int(c)) for a, b, c in
+                re.findall(r'start-time=(\S+) end-time=(\S+) speaker=speaker_(\d+)', final)]
+        got = [(a, b, int(c)) for a, b, c in out[0].tolist()]
+        if got != want:
+            raise SystemExit('bench.py: the batch pipeline and the file-based scripts disagree on file 0')
+        verified = {'file0_rows': len(want), 'against': 'spk-change-detection.py + spk-clustering.py (file based, HIP engine)'}
+    digest0 = rows_digest(out) if out is not None else None
+    for _ in range(max(0, args.warmup - 1)):
         out = step()
     timings = {}
     barrier()
@@ -154,17 +258,25 @@ def main():
         tdt = torch.tensor([dt], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
-        if rank == 0:
-            assert out is not None and len(out) == world * args.files, 'recipe gather incomplete'
+    if rank == 0:
+        assert out is not None and len(out) == world * args.files, 'recipe gather incomplete'
+        if rows_digest(out) != digest0:
+            raise SystemExit('bench.py: a timed step produced different rows than the verified step')
+        verified['digest'] = digest0[:16]
+        verified['files_gathered'] = len(out)
+        if args.dump_rows:
+            np.savez(args.dump_rows, **{'f%d' % i: r for i, r in out.items()})
     hours = world * args.files * (args.seconds / 3600.0) * args.steps
     value = hours / dt
 
     if rank == 0:
         avg = lambda k: float(np.mean(timings[k])) if timings.get(k) else 0.0
+        n_sets = timings.get('stats_sets', 0)
+        gw_bytes = timings.get('gw_frames', 0) * BYTES_PER_FRAME + (n_sets * REC_BYTES if fused else 0)
         kernels = {
-            'k_gw': (avg('gw'), timings.get('gw_frames', 0) * BYTES_PER_FRAME),
+            'k_gw': (avg('gw'), gw_bytes),
             'k_chunk_stats': (avg('chunk_stats'), timings.get('stats_frames', 0) * BYTES_PER_FRAME +
-                              timings.get('stats_sets', 0) * REC_BYTES),
+                              (timings.get('stats_recomputed', n_sets)) * REC_BYTES),
             'k_matrix': (avg('matrix'), timings.get('matrix_pairs', 0) * BYTES_PER_PAIR),
             'k_ahc': (avg('ahc'), timings.get('ahc_pairs', 0) * BYTES_PER_PAIR),
         }
@@ -179,17 +291,21 @@ def main():
         pair_rate = 0.0
         if avg('matrix') > 0:
             pair_rate = timings.get('matrix_pairs', 0) / (avg('matrix') / 1e3)
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # HBM traffic per launch from the PMC passes of THIS build (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate runs; 2 x FETCH + WRITE: the gfx950 FETCH_SIZE halving was
-        # calibrated on k_chunk_stats, whose read volume is known exactly) -- only valid
-        # for the workload those passes were taken on
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01e_bench256_hbm_traffic.json')
-        if (args.files, args.seconds, args.speakers) == (256, 3600.0, 4) and os.path.exists(tfile):
-            with open(tfile) as f:
+        # calibrated on k_chunk_stats, whose read volume is known exactly).  The profile stores
+        # the kernel's duration; a build whose kernel runs at another speed is another build.
+        traffic, traffic_note = None, 'no PMC profile for this workload'
+        if (args.files, args.seconds, args.speakers, fused) == (256, 3600.0, 4, True) and os.path.exists(TRAFFIC_PROFILE):
+            with open(TRAFFIC_PROFILE) as f:
                 tk = json.load(f)['kernels'].get(dom)
-            if tk:
+            if tk and tk.get('kernel_ms') and abs(tk['kernel_ms'] - dms) <= 0.05 * dms:
                 traffic = int(tk['hbm_bytes_per_launch_fetch_doubled'])
+                traffic_note = 'profiles/%s (kernel %.1f ms there, %.1f ms now)' % (
+                    os.path.basename(TRAFFIC_PROFILE), tk['kernel_ms'], dms)
+            elif tk:
+                traffic_note = 'profile is of another build (kernel %.1f ms there, %.1f ms now)' % (
+                    tk.get('kernel_ms') or 0.0, dms)
         res = {
             'metric': 'diarized audio throughput (CD gw/BIC + CL hi/BIC)',
             'value': value, 'unit': 'hours-audio/s', 'n_gpus': world, 'steps': args.steps,
@@ -198,23 +314,73 @@ def main():
             'xRT': value * 3600.0,
             'bic_pair_dists_per_s': pair_rate,
             'config': {'workload': '%d x %.0f s synthetic 16 kHz-equivalent features (39-dim, 125 fps), '
-                                   '%d speakers, per GPU per step; %d distinct sessions tiled; DIA2 flags '
-                                   '(CD -m gw -d BIC -w 1.0 -st 3.0 -dws 0.1 -l 1.0; CL -m hi -l 1.3)'
-                                   % (args.files, args.seconds, args.speakers, len(sessions)),
+                                   '%d speakers, per GPU per step; %d distinct sessions; DIA2 flags '
+                                   '(CD -m gw -d BIC -w 1.0 -st 3.0 -dws 0.1 -l 1.0; CL -m hi -l 1.3); %s'
+                                   % (args.files, args.seconds, args.speakers, n_distinct,
+                                      'frames read once (segment statistics emitted by the change detector)'
+                                      if fused else 'frames read once per stage'),
                        'files_per_gpu': args.files, 'frames_per_file': int(T),
-                       'segments_per_step': timings.get('stats_sets', 0),
+                       'segments_per_step': n_sets,
+                       'segments_recomputed_from_frames': timings.get('stats_recomputed', n_sets),
                        'parallelism': 'file-sharded x%d, no data-path collective' % world},
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic},
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'traffic_source': traffic_note},
             'kernels': per_kernel,
             'wall_ms': {k[5:]: round(float(np.mean(v)), 2) for k, v in timings.items() if k.startswith('wall_')},
             'device_ms_per_step': round(sum(v[0] for v in kernels.values()) + avg('cluster_prep') + avg('reduce_sets'), 3),
+            'verified': verified,
         }
+        if world == 1 and not args.no_extras:
+            res['hbm_copy_GBps'] = round(copy_rate(torch, dev), 1)
+            res['other_configs'] = other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, local)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, synth, cli)
+            res['cpu_baseline_stats'] = cpu_baseline_stats(args, synth, cli)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def copy_rate(torch, dev):
+    """Device-to-device copy of 2 GiB: bytes read + bytes written per second."""
+    n = 1 << 29
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * a.numel() * 4 / 1e9 / (e0.elapsed_time(e1) / 1e3)
+
+
+def other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, local):
+    """BASELINE.json configs 2, 3 and 5 as single-file calls on the same context:
+    wall latency of CD + CL per file (median of 5), with the kernel shares."""
+    out = {}
+    for name, secs, spk in (('config2_1h_4spk', 3600.0, 4), ('config3_1h_8spk', 3600.0, 8),
+                            ('config5_10h_8spk', 36000.0, 8)):
+        feats, vad, _ = synth_device.make_session_device(424242, secs, spk, device=dev)
+        f = [pipeline.BatchFile(0, int(feats.shape[0]), vad_times(vad))]
+        torch.cuda.synchronize()
+        walls, tm = [], {}
+        rows = None
+        for it in range(6):
+            tm = {}
+            t0 = time.perf_counter()
+            rows = pipeline.diarize_batch(ctx, feats.data_ptr(), int(feats.shape[0]), f, timings=tm, fused=True)
+            walls.append(1e3 * (time.perf_counter() - t0))
+        g = lambda k: round(float(np.mean(tm[k])), 3) if tm.get(k) else 0.0
+        out[name] = {'ms': round(float(np.median(walls[1:])), 3), 'segments': int(len(rows[0])),
+                     'speakers_found': int(rows[0][:, 2].max()) if len(rows[0]) else 0,
+                     'xRT': round(secs / (float(np.median(walls[1:])) / 1e3), 0),
+                     'k_gw_ms': g('gw'), 'k_matrix_ms': g('matrix'), 'ahc_ms': g('ahc')}
+        del feats
+    return out
 
 
 if __name__ == '__main__':

@@ -150,8 +150,9 @@ typedef struct {         /* one logged candidate evaluation */
  *   h_final_start[t]     `start` when the loop ended (the tail line starts here)
  * h_log may be NULL (log_cap 0); *h_log_count receives the number of records the
  * run wanted to write (SPKD_EOVERFLOW if > log_cap).
- * Device scratch held by the context: one 10 368-byte record of running moment sums
- * per candidate slot, about turn_len / (rate / 10) slots per turn (0.83 KB per frame).
+ * Device scratch held by the context: one SPKD_REC record (6 560 bytes) of running
+ * moment sums per candidate slot, about turn_len / (rate / 10) slots per turn (0.52 KB
+ * per frame).
  */
 int64_t spkd_gw_event_capacity(int64_t turn_len, double rate);
 /* the bound for any window step (spkd_gw_event_capacity assumes winstep >= 0.2 * rate,
@@ -177,6 +178,30 @@ spkd_status spkd_gw_ex(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
                        double *h_det_start, double *h_det_maxi, double *h_det_d,
                        double *h_final_start,
                        spkd_cand_log *h_log, int64_t log_cap, int64_t *h_log_count);
+
+/* Fused mode: spkd_gw_ex that also leaves the packed statistics
+ * record of every segment it emits, so that the clustering stage does not have to read
+ * the frames again.  Turn t with n_det detections writes n_det + 1 records (the tail
+ * segment [final_start, turn end) last) at d_seg_stats[(h_ev_off[t] + j) * SPKD_REC];
+ * d_seg_stats must hold h_ev_off[n_turns] records (only the written ones are touched),
+ * and a turn needs capacity >= n_det + 1 (else SPKD_EOVERFLOW).  Record j of a turn is
+ * the moment sum of the turn frames [int(det_start[j]), int(det_start[j] + det_maxi[j]))
+ * -- the caller decides per segment whether that is the range its clustering stage would
+ * cut (it is, unless the 12-digit time round trip of SURVEY.md A-2 moved an edge). */
+spkd_status spkd_gw_fused(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
+                          const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
+                          const spkd_cd_params *params, const int64_t *h_ev_off, int check_capacity,
+                          int32_t *h_n_win, double *h_win_maxd, int32_t *h_win_det,
+                          double *h_det_start, double *h_det_maxi, double *h_det_d,
+                          double *h_final_start, double *d_seg_stats,
+                          spkd_cand_log *h_log, int64_t log_cap, int64_t *h_log_count);
+
+/* d_dst[h_dst_index[i]] = d_src[h_src_index[i]] for i < n, whole records
+ * (h_dst_index = NULL: destination i).  Compacts the sparse output of spkd_gw_fused
+ * into the contiguous per-problem layout spkd_ahc reads. */
+spkd_status spkd_gather_stats(spkd_ctx *ctx, const double *d_src, int64_t n_src,
+                              const int64_t *h_src_index, const int64_t *h_dst_index,
+                              int64_t n, int64_t n_dst, double *d_dst);
 
 /* Sliding-window distances, the per-window part of dist_sw
  * (spk-change-detection.py:304-312): window w of turn t compares

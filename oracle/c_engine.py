@@ -50,6 +50,7 @@ def _load():
     lib.orc_gw_turn.argtypes = [vp, i64, C.POINTER(CdParams), i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.orc_sw_turn.argtypes = [vp, i64, C.POINTER(CdParams), vp]
     lib.orc_ahc.argtypes = [vp, i64, C.POINTER(AhcParams), vp, vp, vp, vp, vp, vp]
+    lib.orc_set_threads.argtypes = [C.c_int]
     return lib
 
 
@@ -58,8 +59,11 @@ def _p(a):
 
 
 class COracleEngine(object):
-    def __init__(self):
+    def __init__(self, threads=0):
+        """threads: OpenMP threads of the clustering loops (0 = all cores, 1 = the scalar
+        port); results do not depend on it."""
         self.lib = _load()
+        self.threads = self.lib.orc_set_threads(int(threads))
         self.f = None
 
     def set_features(self, feats):
@@ -123,8 +127,15 @@ class COracleEngine(object):
     def gw(self, turns, kind, lambdac, threshold, winsize, winstep, deltaws, rate, trace=False):
         p = CdParams(KINDS[kind], 1 if trace else 0, lambdac, threshold, winsize, winstep, deltaws, rate)
         out = []
-        for (f0, f1) in turns:
-            nw, wm, wd, ds, dm, dd, fin, log, cnt = self.gw_raw(f0, f1, p, (1 << 20) if trace else 4096)
+        # turns are independent: one C call each, run side by side (ctypes drops the GIL)
+        log_cap = (1 << 20) if trace else 4096
+        if len(turns) > 1 and self.threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=self.threads) as pool:
+                raw = list(pool.map(lambda t: self.gw_raw(t[0], t[1], p, log_cap), turns))
+        else:
+            raw = [self.gw_raw(f0, f1, p, log_cap) for (f0, f1) in turns]
+        for (nw, wm, wd, ds, dm, dd, fin, log, cnt) in raw:
             by_win = {}
             for k in range(cnt):
                 by_win.setdefault(log[k].win, []).append(log[k])

@@ -24,6 +24,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define D 39
 #define DA 40
@@ -430,6 +433,29 @@ static double cluster_distance(int kind, double lambdac, const double *ra, doubl
     return glr_terms(n1, lda, n2, ldb, logdet(S1, nf));
 }
 
+/* Threads: the pair distances of a clustering problem are independent, so the loops over
+ * them (and the scans of the matrix) are OpenMP loops.  Every distance is still computed
+ * by the same scalar code on one thread and every reduction is combined in index order,
+ * so results do not depend on the thread count.  orc_set_threads(1) gives the scalar
+ * port, orc_set_threads(0) all cores; orc_get_threads() what a parallel region gets. */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
+int orc_get_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* stats: n records (copied; merged in place on the copy).  merge_a/b/d: capacity n.
  * stat_max / stat_min as spkd_ahc. */
 int orc_ahc(const double *stats_in, int64_t n, const orc_ahc_params *P, int32_t *n_merges,
@@ -438,10 +464,13 @@ int orc_ahc(const double *stats_in, int64_t n, const orc_ahc_params *P, int32_t 
     double *st = (double *)malloc((size_t)n * REC * sizeof(double));
     double *ld = (double *)malloc((size_t)n * sizeof(double));
     double *dm = (double *)malloc((size_t)n * n * sizeof(double));
+    double *dm2 = (double *)malloc((size_t)n * n * sizeof(double));  /* np.delete target */
     int64_t *ids = (int64_t *)malloc((size_t)n * sizeof(int64_t));   /* compacted position -> slot */
-    if (!st || !ld || !dm || !ids) { free(st); free(ld); free(dm); free(ids); return -1; }
+    double *rs = (double *)malloc((size_t)(4 * n + 8) * sizeof(double));   /* per-row scan results */
+    if (!st || !ld || !dm || !dm2 || !ids || !rs) { free(st); free(ld); free(dm); free(dm2); free(ids); free(rs); return -1; }
     memcpy(st, stats_in, (size_t)n * REC * sizeof(double));
     double smax = NAN, smin = NAN;
+#pragma omp parallel for schedule(static) reduction(|:nf)
     for (int64_t i = 0; i < n; ++i) {
         ids[i] = i;
         ld[i] = P->kind == ORC_KL2 ? 0.0 : orc_logdet_cov(st + i * REC, &nf);
@@ -452,23 +481,45 @@ int orc_ahc(const double *stats_in, int64_t n, const orc_ahc_params *P, int32_t 
         for (int64_t j = 0; j < n; ++j) dm[i * n + j] = P->variant == 1 ? (i == j ? MAXINT_F : 0.0) : INFINITY;
 #define NOTE(d) do { if ((d) == (d) && fabs(d) < INFINITY) { \
         if (smax != smax || (d) > smax) smax = (d); if (smin != smin || (d) < smin) smin = (d); } } while (0)
+#pragma omp parallel for schedule(dynamic, 4) reduction(|:nf)
     for (int64_t i = 0; i < n; ++i)
         for (int64_t j = i + 1; j < n; ++j) {
             const double d = cluster_distance(P->kind, P->lambdac, st + i * REC, ld[i], st + j * REC, ld[j], &nf);
             dm[i * n + j] = d;
-            if (P->variant == 1) { dm[j * n + i] = d; NOTE(d); }
+            if (P->variant == 1) dm[j * n + i] = d;
         }
+    if (P->variant == 1)
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t j = i + 1; j < n; ++j) NOTE(dm[i * n + j]);
     int nm = 0;
     double fmax = NAN, fmin = NAN;
     for (;;) {
-        /* numpy min / argmin over the m x m compacted matrix (row stride m) */
+        /* numpy min / argmin over the m x m compacted matrix (row stride m): per-row
+         * partial results, combined in row order (first occurrence wins) */
         double mind = INFINITY, mx = -INFINITY;
         int64_t idx = -1, nan_idx = -1;
-        for (int64_t l = 0; l < m * m; ++l) {
-            const double v = dm[l];
-            if (v != v) { if (nan_idx < 0) nan_idx = l; continue; }
-            if (idx < 0 || v < mind) { mind = v; idx = l; }
-            if (v > mx) mx = v;
+        {
+            double *rmin = rs, *rmax = rs + m;
+            int64_t *ridx = (int64_t *)(rs + 2 * m), *rnan = ridx + m;
+            {
+#pragma omp parallel for schedule(static)
+                for (int64_t r = 0; r < m; ++r) {
+                    double mv = INFINITY, xv = -INFINITY;
+                    int64_t mi = -1, ni = -1;
+                    for (int64_t c = 0; c < m; ++c) {
+                        const double v = dm[r * m + c];
+                        if (v != v) { if (ni < 0) ni = r * m + c; continue; }
+                        if (mi < 0 || v < mv) { mv = v; mi = r * m + c; }
+                        if (v > xv) xv = v;
+                    }
+                    rmin[r] = mv; rmax[r] = xv; ridx[r] = mi; rnan[r] = ni;
+                }
+                for (int64_t r = 0; r < m; ++r) {
+                    if (rnan[r] >= 0 && nan_idx < 0) nan_idx = rnan[r];
+                    if (ridx[r] >= 0 && (idx < 0 || rmin[r] < mind)) { mind = rmin[r]; idx = ridx[r]; }
+                    if (rmax[r] > mx) mx = rmax[r];
+                }
+            }
         }
         if (nan_idx >= 0) { mind = NAN; idx = nan_idx; mx = NAN; }
         fmax = mx;
@@ -485,28 +536,32 @@ int orc_ahc(const double *stats_in, int64_t n, const orc_ahc_params *P, int32_t 
         const double *rb = st + ids[b] * REC;
         for (int e = 0; e < REC; ++e) ra[e] += rb[e];
         /* np.delete(row b), np.delete(col b) */
-        int64_t w = 0;
-        for (int64_t i = 0; i < m; ++i) {
-            if (i == b) continue;
-            for (int64_t j = 0; j < m; ++j) {
-                if (j == b) continue;
-                dm[w++] = dm[i * m + j];
-            }
+#pragma omp parallel for schedule(static)
+        for (int64_t i2 = 0; i2 < m - 1; ++i2) {
+            const double *src = dm + (i2 < b ? i2 : i2 + 1) * m;
+            double *dst = dm2 + i2 * (m - 1);
+            for (int64_t j = 0; j < b; ++j) dst[j] = src[j];
+            for (int64_t j = b + 1; j < m; ++j) dst[j - 1] = src[j];
         }
+        { double *t = dm; dm = dm2; dm2 = t; }
         for (int64_t i = b; i + 1 < m; ++i) ids[i] = ids[i + 1];
         --m;
         if (P->kind != ORC_KL2) ld[ids[a]] = orc_logdet_cov(ra, &nf);
+#pragma omp parallel for schedule(dynamic, 8) reduction(|:nf)
         for (int64_t s2 = 0; s2 < m; ++s2) {
             if (s2 == a) continue;
             const double d = cluster_distance(P->kind, P->lambdac, ra, ld[ids[a]], st + ids[s2] * REC,
                                               ld[ids[s2]], &nf);
             dm[a * m + s2] = d;
-            if (P->variant == 1) { dm[s2 * m + a] = d; NOTE(d); }
+            if (P->variant == 1) dm[s2 * m + a] = d;
         }
+        if (P->variant == 1)
+            for (int64_t s2 = 0; s2 < m; ++s2)
+                if (s2 != a) NOTE(dm[a * m + s2]);
     }
     *n_merges = nm;
     if (P->variant == 1) { *stat_max = smax; *stat_min = smin; }
     else { *stat_max = fmax; *stat_min = fmin; }
-    free(st); free(ld); free(dm); free(ids);
+    free(st); free(ld); free(dm); free(dm2); free(ids); free(rs);
     return nf ? 1 : 0;
 }

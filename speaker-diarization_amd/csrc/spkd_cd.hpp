@@ -181,10 +181,21 @@ __device__ __forceinline__ void log_cand(spkd_cand_log* log, long long cap, unsi
 enum { PASS_RIGHT = 0, PASS_LEFT = 1, PASS_GLR = 2, PASS_POOLED = 3 };
 
 // ---------------------------------------------------------------------------
-// Packed lower-triangle record ("tri record") of the augmented moment matrix, in
-// the quad lane layout: line (tri_off(s) + j) holds M(13 s + t, j) for t = 0..12
-// in its first 13 doubles, j < 13 (s + 1); lines 78..80 hold the sums column of
-// slot s; the frame count sits in lane 15 of line 78.  81 lines of 128 B.
+// Records of running moment sums.
+//
+// In LDS (P(c), the sums at the window end) the "tri" layout: line (tri_off(s) + j)
+// holds M(13 s + t, j) for t = 0..12 in its first 13 doubles, j < 13 (s + 1); lines
+// 78..80 hold the sums column of slot s; the frame count sits in lane 15 of line 78.
+// 81 lines of 128 B, conflict-free for the formation's reads.
+//
+// In global memory (the per-candidate cache, and the per-segment output of the fused
+// mode) the ABI's packed record itself, SPKD_REC = 820 doubles.  Read by symmetry it
+// is the lower triangle column by column: column j holds rows j .. 39 contiguously
+// from pk_off(j), so the quad load of (slot s, column j) is 13 consecutive doubles at
+// pk_off(j) + 13 s - j + t.  For the lanes of a diagonal block that sit above the
+// diagonal (13 s + t < j) that address lies in the tail of the previous column --
+// inside the record, and the value lands in a register nobody reads (spkd_tri.hpp).
+// 6 560 B per candidate instead of the 10 368 B of a padded tri record.
 // ---------------------------------------------------------------------------
 constexpr int TLINES = 3 * QL + 3 * QL + 3;                  // 13 + 26 + 39 + 3 = 81
 constexpr int TREC = TLINES * 16;                            // 1 296 doubles = 10 368 B
@@ -199,7 +210,10 @@ __device__ __forceinline__ int tri_slot(int r, int j) {
     return TREC_COUNT_AT;
 }
 
-// row-per-lane (single matrix) rows of a tri record, by symmetry
+// the same entry in a packed record (= pk(j, r): upper triangle row-major by symmetry)
+__host__ __device__ constexpr int pk_low(int r, int j) { return pk_off(j) + (r - j); }
+
+// row-per-lane (single matrix) rows of a tri record / a packed record, by symmetry
 __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (&q)[DA]) {
     int i = lane_id();
     i = i >= D ? D - 1 : i;
@@ -208,12 +222,20 @@ __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (
     q[D] = rec[tri_slot(D, i)];
 }
 
+__device__ __forceinline__ void single_rows_from_packed(const double* __restrict__ rec, double (&q)[DA]) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] = rec[j <= i ? pk_low(i, j) : pk_low(j, i)];
+    q[D] = rec[pk_low(D, i)];
+}
+
 // ---------------------------------------------------------------------------
 // The sweep: threads 0..209 own one 2x2 block of the lower triangle of the 40x40
-// augmented matrix each (column-major over the 20x20 block grid, so that
-// consecutive lanes hold consecutive rows: dumps are half-coalesced).  Per frame a
+// augmented matrix each (column-major over the 20x20 block grid).  Per frame a
 // thread reads x[2 bi .. 2 bi + 1] and x[2 bj .. 2 bj + 1] from the float tile and
-// issues four fp64 FMAs.
+// issues four fp64 FMAs.  A block is two pairs of vertically adjacent entries, i.e.
+// two 16-byte pieces of a packed record.
 // ---------------------------------------------------------------------------
 constexpr int GW_WAVES = 4;
 constexpr int GW_TPB = GW_WAVES * WAVE;
@@ -228,6 +250,7 @@ constexpr int GW_TILE = 128;                                 // frames per LDS t
 struct SweepLane {
     int bi, bj;
     bool on;
+    int o0, o1;          // packed-record offsets of (2 bi, 2 bj) and of the block's second column
 };
 
 __device__ __forceinline__ SweepLane sweep_lane(int tid) {
@@ -237,11 +260,15 @@ __device__ __forceinline__ SweepLane sweep_lane(int tid) {
     while (rem >= 20 - bj) { rem -= 20 - bj; ++bj; }
     s.bj = bj;
     s.bi = bj + rem;
+    const int r0 = 2 * s.bi, j0 = 2 * s.bj;
+    s.o0 = pk_low(r0, j0);
+    // off-diagonal blocks: (r0, j0 + 1), (r0 + 1, j0 + 1); diagonal blocks: only (r0 + 1, j0 + 1)
+    s.o1 = s.bi > s.bj ? pk_low(r0, j0 + 1) : pk_low(r0 + 1, j0 + 1);
     return s;
 }
 
-template <class Ptr>
-__device__ __forceinline__ void sweep_dump(Ptr rec, const SweepLane& SL, const double (&acc)[4]) {
+// acc[0..3] = (r0, j0), (r0, j0 + 1), (r0 + 1, j0), (r0 + 1, j0 + 1)
+__device__ __forceinline__ void sweep_dump_lds(double* rec, const SweepLane& SL, const double (&acc)[4]) {
     if (!SL.on) return;
     const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
     rec[tri_slot(r0, j0)] = acc[0];
@@ -250,12 +277,24 @@ __device__ __forceinline__ void sweep_dump(Ptr rec, const SweepLane& SL, const d
     rec[tri_slot(r0 + 1, j0 + 1)] = acc[3];
 }
 
-__device__ __forceinline__ void sweep_gather(const SPKD_GLOBAL double* rec, const SweepLane& SL, double (&acc)[4]) {
-    const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
-    acc[0] = rec[tri_slot(r0, j0)];
-    acc[1] = (SL.bi > SL.bj) ? rec[tri_slot(r0, j0 + 1)] : 0.0;
-    acc[2] = rec[tri_slot(r0 + 1, j0)];
-    acc[3] = rec[tri_slot(r0 + 1, j0 + 1)];
+__device__ __forceinline__ void sweep_dump_packed(SPKD_GLOBAL double* rec, const SweepLane& SL, const double (&acc)[4]) {
+    if (!SL.on) return;
+    rec[SL.o0] = acc[0];
+    rec[SL.o0 + 1] = acc[2];
+    if (SL.bi > SL.bj) {
+        rec[SL.o1] = acc[1];
+        rec[SL.o1 + 1] = acc[3];
+    } else {
+        rec[SL.o1] = acc[3];
+    }
+}
+
+__device__ __forceinline__ void sweep_gather_packed(const SPKD_GLOBAL double* rec, const SweepLane& SL, double (&acc)[4]) {
+    const bool off = SL.bi > SL.bj;
+    acc[0] = rec[SL.o0];
+    acc[2] = rec[SL.o0 + 1];
+    acc[1] = off ? rec[SL.o1] : 0.0;
+    acc[3] = off ? rec[SL.o1 + 1] : rec[SL.o1];
 }
 
 // Adds the turn frames [pos, ...) to acc in frame order.  `want` is the next
@@ -281,10 +320,15 @@ __device__ __forceinline__ void sweep_issue(const SPKD_GLOBAL float* fr, long lo
     const int tl = (int)(left < GW_TILE ? (left < 0 ? 0 : left) : GW_TILE);
     const SPKD_GLOBAL float* src = fr + pos * D;
     const int nfl = tl * D;
+    if (nfl > 0) {                       // (uniform) nothing left: element 0 would lie behind `limit`
 #pragma unroll
-    for (int u = 0; u < GW_STAGE; ++u) {
-        const int idx = t + u * GW_TPB;
-        st[u] = src[idx < nfl ? idx : 0];
+        for (int u = 0; u < GW_STAGE; ++u) {
+            const int idx = t + u * GW_TPB;
+            st[u] = src[idx < nfl ? idx : 0];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < GW_STAGE; ++u) st[u] = 0.0f;
     }
 }
 
@@ -356,7 +400,7 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
 #endif
 }
 
-// The two uses of the sweep, as real functions: compiled apart from the kernel body
+// The uses of the sweep, as real functions: compiled apart from the kernel body
 // they keep their few live values in registers.  Inlined into k_gw they share its
 // register allocation with the elimination code, the allocator spills the sweep's
 // loop invariants, and every reload (a scratch load, counted with the global stores
@@ -387,7 +431,7 @@ __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, d
     const long long want = built_k < C ? (long long)(start + built_i) : c;
     gw_sweep(gfr, xs, SL, tid, acc, sweep_pos, want, c, [&](long long pos) -> long long {
         if (built_k < C) {
-            sweep_dump(gcache + built_k * TREC, SL, acc);
+            sweep_dump_packed(gcache + built_k * REC, SL, acc);
             ++built_k;
             built_i += istep;
             if (built_k == C) {             // the sweep rests here until the window grows
@@ -397,7 +441,7 @@ __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, d
             }
             return built_k < C ? (long long)(start + built_i) : c;
         }
-        sweep_dump(ldsEnd, SL, acc);        // pos == c
+        sweep_dump_lds(ldsEnd, SL, acc);    // pos == c
         return -1;
     }, err);
     SweepOut o;
@@ -420,15 +464,31 @@ __device__ __noinline__ void gw_sweep_fine(const float* __restrict__ fr, double*
     const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
     SPKD_GLOBAL double* gcache = (SPKD_GLOBAL double*)cache;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (base) sweep_gather((const SPKD_GLOBAL double*)base, SL, acc);
+    if (base) sweep_gather_packed((const SPKD_GLOBAL double*)base, SL, acc);
     double fx = fine_i0;
     long long fk = 0;
     const long long last = (long long)(start + (fine_i0 + (double)(F - 1)));
     gw_sweep(gfr, xs, SL, tid, acc, base_pos, (long long)(start + fx), last, [&](long long) -> long long {
-        sweep_dump(gcache + (first_slot + fk) * TREC, SL, acc);
+        sweep_dump_packed(gcache + (first_slot + fk) * REC, SL, acc);
         ++fk;
         fx += 1;
         return fk < F ? (long long)(start + fx) : -1;
+    }, err);
+}
+
+// fused mode, tail segment: the moments of the turn frames [from, to) -> one packed record
+__device__ __noinline__ void gw_sweep_tail(const float* __restrict__ fr, long long from, long long to,
+                                           double* __restrict__ out, int* err) {
+    extern __shared__ double gw_lds[];
+    float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
+    const int tid = threadIdx.x;
+    const SweepLane SL = sweep_lane(tid);
+    const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
+    SPKD_GLOBAL double* gout = (SPKD_GLOBAL double*)out;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    gw_sweep(gfr, xs, SL, tid, acc, from, to, to, [&](long long) -> long long {
+        sweep_dump_packed(gout, SL, acc);
+        return -1;
     }, err);
 }
 
@@ -444,7 +504,7 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
         cov_rows(q, n);
         return;
     }
-    single_rows_from_tri(rec_b, q);
+    single_rows_from_packed(rec_b, q);
     if (pass == PASS_LEFT) {
         cov_rows(q, n1);
         return;
@@ -470,9 +530,9 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
 }
 
 // log det of four (pass, split point) items held by the wave: DPP row m forms the
-// matrix of ITS pass for ITS split b (cache record rec_b) -- the passes of a scan
-// are packed four to a wave whatever their kind, so `pass` is a per-lane value and
-// everything below is straight-line code with per-lane coefficients:
+// matrix of ITS pass for ITS split b (packed cache record rec_b) -- the passes of a
+// scan are packed four to a wave whatever their kind, so `pass` is a per-lane value
+// and everything below is straight-line code with per-lane coefficients:
 //     q  = al * P(b) + ga * P(c)                (lower triangle + sums column)
 //     q += c1 v1^T + c2 v2^T   (al, ga, c1 carry the covariance scale f)
 //   right  [b, c): al = -1, ga = 1; v1 = s_c - s_b, c1 = -v1 / n2;  f = 1 / (n2 - 1)
@@ -481,7 +541,8 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
 //                  (rec_b: any valid record, it is multiplied by zero)
 //   GLR: al1 P(b) + al2 (P(c) - P(b)) - be1 s1 s1^T - be2 s2 s2^T;  f = 1
 // two: the launch has GLR items (wave-uniform; the second rank-one term is skipped
-// otherwise).
+// otherwise).  DPP rows that name the same record (the left and the right item of a
+// new candidate sit side by side) fetch it once: their loads coalesce.
 __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const double* ldsEnd,
                                                     const double* __restrict__ rec_b,
                                                     double n1, double n2, const QuadLane& L, int* err) {
@@ -512,20 +573,21 @@ __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const do
         // 81 loads in flight, one latency.  One base pointer per 4 KB (the immediate
         // offset of a global load spans 4 KB; left to itself the compiler builds a
         // separate address for every load, spills them and serialises the loads)
-        const double* rt[3];
-        long long o1 = 512, o2 = 1024;      // opaque, so that the bases stay separate registers
-        asm volatile("" : "+v"(o1), "+v"(o2));
-        rt[0] = rec_b + L.t;
+        const int t12 = ta < QL ? ta : QL - 1;          // idle lanes 13..15 ride with lane 12
+        const double* rt[2];
+        long long o1 = 512;                 // opaque, so that the bases stay separate registers
+        asm volatile("" : "+v"(o1));
+        rt[0] = rec_b + t12;
         rt[1] = rt[0] + o1;
-        rt[2] = rt[0] + o2;
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
 #pragma unroll
             for (int j = 0; j < tri_cols(s); ++j) {
-                const int line = tri_off(s) + j;
-                q.r[s][j] = rt[line / 32][(line % 32) * 16];
+                const int e = pk_off(j) + QL * s - j;   // + t12 (in the base)
+                q.r[s][j] = rt[e / 512][e % 512];
             }
-            svb[s] = rt[(TREC_SUMS + s) / 32][((TREC_SUMS + s) % 32) * 16];
+            const int c = QL * s + t12;                 // this lane's row of slot s
+            svb[s] = rec_b[pk_off(c) + D - c];          // (39, c): the sums entry of column c
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -559,12 +621,19 @@ constexpr int GW_LDS_BYTES = TREC * 8 + 4 * GW_TPB * 8 + GW_TILE * DA * 4;
 //
 // Candidate scratch per slot k: c_i = i value, c_left = memoised left term (BIC:
 // 0.5 N1 log det S1; GLR: log det S1), c_x = right log det / finished distance;
-// cache record k = P(b_k).
+// cache record k = P(b_k), a packed record.
 //
 // The kernel is one loop over "scans": a coarse scan over the candidates
 // i = minfeas, minfeas + istep, ... (CD:204-221) and, after a positive one, a
 // fine scan over single-frame steps around the maximum (CD:235-251).  Both kinds
 // share one body, so the elimination code exists once.
+//
+// Fused mode (seg_stats != nullptr): every segment the detector emits -- [start,
+// start + maxi) of a detection, [final start, turn end) of the tail -- also leaves its
+// packed statistics record, which is what the clustering stage needs (the frames are
+// then read once for both stages): a detection's record is the cache record of the
+// chosen split point, the tail's is P(turn end) of the last epoch.  Record j of turn t
+// lands at seg_stats[(ev_off[t] + j) * 820], j = 0 .. n_det (the tail last).
 #ifdef SPKD_PROFILE
 #define GW_TICK(i) do { const unsigned long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
 #else
@@ -586,9 +655,12 @@ struct GwState {
     // addition as cur_i, so the same doubles)
     long long built_k, sweep_pos;
     long long best_k, F, base, count;
+    long long seg_src, seg_dst;    // fused mode: cache slot -> output record of the detection just made
     int nw, nd;
     int fine;              // kind of the scan about to run
-    int go;                // the outer loop continues
+    int go;                // the outer loop continues (written in the decision step only)
+    int abort;             // a capacity ran out while the scan was being set up
+    int tail_in_lds;       // the loop ended on a negative scan whose window end is the turn end
 };
 
 __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
@@ -596,8 +668,8 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         double* __restrict__ cache_all, double* __restrict__ cand_all,
         int32_t* __restrict__ n_win, double* __restrict__ win_maxd, int32_t* __restrict__ win_det,
         double* __restrict__ det_start, double* __restrict__ det_maxi, double* __restrict__ det_d,
-        double* __restrict__ final_start, spkd_cand_log* clog, long long log_cap,
-        unsigned long long* log_count, int* err) {
+        double* __restrict__ final_start, double* __restrict__ seg_stats, spkd_cand_log* clog,
+        long long log_cap, unsigned long long* log_count, int* err) {
     extern __shared__ double gw_lds[];
     double* ldsEnd = gw_lds;                         // P(c), tri record
     double* persist = gw_lds + TREC;                 // [4][GW_TPB]: the sweep's sums at sweep_pos
@@ -610,7 +682,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     const int turn = (int)T.id;
     const long long n = T.len;
     const float* fr = frames + T.begin * D;
-    double* cache = cache_all + T.cand_off * TREC;
+    double* cache = cache_all + T.cand_off * REC;
     const long long cap = T.cand_cap;
     double* c_i = cand_all + 4 * T.cand_off;
     double* c_left = c_i + cap;
@@ -620,10 +692,9 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 #ifdef SPKD_PROFILE
     unsigned long long prof_acc[4] = {0ull, 0ull, 0ull, 0ull}, prof_t = clock64(), prof_scans = 0ull;
 #endif
-    for (int e = tid; e < TREC; e += GW_TPB) {
-        ldsEnd[e] = 0.0;
-        cache[e] = 0.0;              // record 0 is read (times zero) by the pooled item even before it is built
-    }
+    for (int e = tid; e < TREC; e += GW_TPB) ldsEnd[e] = 0.0;
+    // record 0 is read (times zero) by the pooled item even before it is built
+    for (int e = tid; e < REC; e += GW_TPB) cache[e] = 0.0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
 
@@ -644,8 +715,11 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         S.n_memo = 0; S.n_written = 0; S.C = 0;
         S.built_k = 0; S.sweep_pos = 0;
         S.best_k = 0; S.F = 0; S.base = 0; S.count = 0;
+        S.seg_src = -1; S.seg_dst = -1;
         S.nw = 0; S.nd = 0; S.fine = 0;
         S.go = (S.end <= fn) ? 1 : 0;
+        S.abort = 0;
+        S.tail_in_lds = 0;
     }
     __syncthreads();
     GW_TICK(0);
@@ -657,7 +731,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             if (!S.fine) {
                 if (S.nw >= T.ev_cap) {
                     atomicOr(err, 4);
-                    S.go = 0;
+                    S.abort = 1;
                 } else {
                     const double lim = S.end - S.start - minfeas;
                     double cur_i = S.cur_i;
@@ -667,6 +741,10 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                         if (C >= n_written) { c_i[C] = cur_i; n_written = C + 1; }
                         ++C;
                         cur_i += istep;
+                    }
+                    if (cur_i < lim) {           // candidate slots exhausted (cannot happen with spkd_gw's sizing)
+                        atomicOr(err, 4);
+                        S.abort = 1;
                     }
                     S.cur_i = cur_i; S.C = C; S.n_written = n_written;
                     S.base = 0;
@@ -681,7 +759,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 S.F = F;
                 if (S.C + F > cap) {
                     atomicOr(err, 4);
-                    S.go = 0;
+                    S.abort = 1;
                 } else {
                     // the fine i sequence, by repeated +1 like the reference
                     double x = fine_i0;
@@ -692,7 +770,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             }
         }
         __syncthreads();
-        if (!S.go) break;
+        if (S.abort) break;                  // (written before the barrier, never reset)
         // ---- (B) the sweep: P(b_k) for the new candidates, then P(c); fine: P at the F
         // single-frame positions, from a coarse candidate two steps below the maximum
         // (always at or below the first fine position)
@@ -708,7 +786,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             } else {
                 const long long best_k = S.best_k;
                 if (best_k >= 2)
-                    gw_sweep_fine(fr, cache, cache + (best_k - 2) * TREC, (long long)(start + c_i[best_k - 2]),
+                    gw_sweep_fine(fr, cache, cache + (best_k - 2) * REC, (long long)(start + c_i[best_k - 2]),
                                   start, S.fine_i0, S.F, C, err);
                 else
                     gw_sweep_fine(fr, cache, nullptr, a, start, S.fine_i0, S.F, C, err);
@@ -724,7 +802,6 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         const long long base = S.base, count = S.count;
         {
         const long long n_memo = S.n_memo;
-        const double N = (double)(c - a);
         const bool pooled = (kind == SPKD_BIC && !fine);
         if (kind == SPKD_KL2) {
             // one wave per split point, single-matrix layout (Gauss-Jordan inverses)
@@ -736,7 +813,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 #pragma unroll 1
                 for (int t = 0; t < 2; ++t) {
                     double a_[DA], r_[DA];
-                    single_rows_from_tri(cache + (base + job) * TREC, a_);
+                    single_rows_from_packed(cache + (base + job) * REC, a_);
                     if (t) {
                         single_rows_from_tri(ldsEnd, r_);
 #pragma unroll
@@ -751,31 +828,49 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 if (lane == 0) c_x[base + job] = dist;
             }
         } else {
-            // the scan's matrices as one list of (pass, candidate) items, four to a wave
-            // whatever their kind: [pooled window] (BIC coarse scans) | right of every
-            // candidate | left of the candidates not memoised yet | GLR's W of every candidate
-            const long long n_pool = pooled ? 1 : 0;
+            // The scan's matrices as one list of (pass, candidate) items, four to a wave
+            // whatever their kind.  Items that read the same cache record sit side by side
+            // in a wave, where their loads coalesce: a candidate whose left term is not
+            // memoised yet (CD:84-90) contributes the pair (left, right), so its record
+            // is fetched once for both.  BIC:
+            //   right of the memoised candidates | [pad to an even index: the pooled window,
+            //   or an idle item] | (left, right) of every new candidate | [the pooled window]
+            // GLR: (right, W) of every candidate | left of the new ones.
             const long long left0 = fine ? 0 : (n_memo < count ? n_memo : count);
-            const long long n_left = count - left0;
+            const long long nnew = count - left0;
             const bool glr_kind = kind == SPKD_GLR;
-            const long long M = n_pool + count + n_left + (glr_kind ? count : 0);
+            const long long padA = glr_kind ? 0 : (left0 & 1);
+            const long long base2 = left0 + padA;
+            const long long M = glr_kind ? 2 * count + nnew
+                                         : base2 + 2 * nnew + ((pooled && !padA) ? 1 : 0);
             for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
                 long long it = 4 * q4 + L.m;
-                const bool valid = it < M;
+                bool valid = it < M;
                 it = valid ? it : M - 1;
                 int pass;
                 long long k;
-                if (it < n_pool) { pass = PASS_POOLED; k = 0; }
-                else if (it < n_pool + count) { pass = PASS_RIGHT; k = it - n_pool; }
-                else if (it < n_pool + count + n_left) { pass = PASS_LEFT; k = left0 + (it - n_pool - count); }
-                else { pass = PASS_GLR; k = it - n_pool - count - n_left; }
+                if (glr_kind) {
+                    if (it < 2 * count) { k = it >> 1; pass = (it & 1) ? PASS_GLR : PASS_RIGHT; }
+                    else { k = left0 + (it - 2 * count); pass = PASS_LEFT; }
+                } else if (it < left0) {
+                    pass = PASS_RIGHT; k = it;
+                } else if (padA && it == left0) {
+                    if (pooled) { pass = PASS_POOLED; k = 0; }
+                    else { pass = PASS_RIGHT; k = it - 1; valid = false; }
+                } else if (it < base2 + 2 * nnew) {
+                    const long long j = it - base2;
+                    k = left0 + (j >> 1);
+                    pass = (j & 1) ? PASS_RIGHT : PASS_LEFT;
+                } else {
+                    pass = PASS_POOLED; k = 0;
+                }
                 const long long slot = base + k;
                 // (no candidates at all: the only item is the pooled window; record 0 is still a
                 // finite record of this or an earlier epoch, or zero-initialised scratch)
                 const double ik = count > 0 ? c_i[slot] : 0.0;
                 const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
                 const double n1 = (double)(b - a), n2 = (double)(c - b);
-                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * TREC, n1, n2, L, err);
+                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err);
                 if (valid && L.t == 0) {
                     if (pass == PASS_POOLED) s_ldS = v;
                     else if (pass == PASS_RIGHT) c_x[slot] = v;
@@ -791,51 +886,58 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 #ifdef SPKD_PROFILE
         ++prof_scans;
 #endif
-        const double N = (double)(c - a);
-        // ---- (D) finish the distances.  GLR: -(N/2) ((N1/N) log|S1| + (N2/N) log|S2| - log|W|)
-        if (kind == SPKD_GLR) {
-            for (long long k = tid; k < count; k += GW_TPB) {
-                const long long slot = base + k;
-                const long long b = (long long)(start + c_i[slot]);
-                const double n1 = (double)(b - a), n2 = (double)(c - b);
-                c_x[slot] = -(N / 2.0) * ((n1 / N) * c_left[slot] + (n2 / N) * c_x[slot] - c_w[slot]);
-            }
-            __syncthreads();
-        }
-        // BIC: d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
-        if (kind == SPKD_BIC) {
-            // (fine scans: s_ldS still holds the pooled term of this window)
+        // ---- (D) finish the distances and take the first-index arg-max in the same pass
+        //   GLR: -(N/2) ((N1/N) log|S1| + (N2/N) log|S2| - log|W|)
+        //   BIC: d = 0.5 N log|S| - c1 - 0.5 N2 log|S2| - penalty
+        //        (fine scans: s_ldS still holds the pooled term of this window)
+        BestD best;
+        {
+            const double N = (double)(c - a);
             const double ldS = s_ldS;
             const double corr = pen_w * log(N);
-            for (long long k = tid; k < count; k += GW_TPB) {
-                const long long slot = base + k;
-                const long long b = (long long)(start + c_i[slot]);
-                const double n2 = (double)(c - b);
-                double d = 0.5 * N * ldS - c_left[slot] - 0.5 * n2 * c_x[slot];
-                d -= corr;
-                c_x[slot] = d;
-            }
-            __syncthreads();
-        }
-        {
             const int nw = S.nw;
+            best.d = fine ? S.maxd : NEG_MAXINT_M1;
+            best.k = -1;
             for (long long k = tid; k < count; k += GW_TPB) {
                 const long long slot = base + k;
-                const double d = c_x[slot];
+                const double ik = c_i[slot];
+                const long long b = (long long)(start + ik);
+                const double n1 = (double)(b - a), n2 = (double)(c - b);
+                double d = c_x[slot];
+                if (kind == SPKD_GLR) {
+                    d = -(N / 2.0) * ((n1 / N) * c_left[slot] + (n2 / N) * d - c_w[slot]);
+                } else if (kind == SPKD_BIC) {
+                    d = 0.5 * N * ldS - c_left[slot] - 0.5 * n2 * d;
+                    d -= corr;
+                }
                 if ((P.trace && !fine) || fabs(d) == __builtin_huge_val()) {
-                    const long long b = (long long)(start + c_i[slot]);
                     const long long w = fine ? (long long)(nw - 1) : (long long)nw;
                     log_cand(clog, log_cap, log_count, turn, fine ? 0 : 1,
-                             (w << 32) | (fine ? 0x80000000LL : 0LL) | k, start, c_i[slot], d, b - a, c - b);
+                             (w << 32) | (fine ? 0x80000000LL : 0LL) | k, start, ik, d, b - a, c - b);
                 }
+                if (d > best.d && d != __builtin_huge_val()) { best.d = d; best.k = k; }   // NaN fails d > best.d
+            }
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) {
+                const double d2 = __shfl_xor(best.d, s);
+                const long long k2 = __shfl_xor(best.k, s);
+                const bool take = (k2 >= 0) && (best.k < 0 || d2 > best.d || (d2 == best.d && k2 < best.k));
+                if (take) { best.d = d2; best.k = k2; }
+            }
+            if (lane == 0) red[wave] = best;
+            __syncthreads();
+            best = red[0];
+            for (int w = 1; w < GW_WAVES; ++w) {
+                const BestD o = red[w];
+                const bool take = (o.k >= 0) && (best.k < 0 || o.d > best.d || (o.d == best.d && o.k < best.k));
+                if (take) best = o;
             }
         }
         GW_TICK(3);
-        // ---- (E) arg-max (all threads), then thread 0 takes the decision (CD:222-284)
+        // ---- (E) thread 0 takes the decision (CD:222-284)
         if (!fine) {
-            const long long C = count;
-            const BestD best = block_argmax<GW_WAVES>(c_x, C, NEG_MAXINT_M1, red);
             if (tid == 0) {
+                const long long C = count;
                 if (C > S.n_memo) S.n_memo = C;
                 const bool found = best.k >= 0;
                 const double maxd = best.d;
@@ -861,21 +963,24 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                         S.go = 1;
                     } else {
                         S.go = 0;
+                        S.tail_in_lds = 1;   // ldsEnd = P(turn end) of this epoch
                     }
                     S.end = end; S.ws = ws; S.dws = dws;
                 }
             }
         } else {
-            const long long C = S.C, F = count;
-            const BestD fb = block_argmax<GW_WAVES>(c_x + C, F, S.maxd, red);
             if (tid == 0) {
+                const long long C = S.C;
                 double maxd = S.maxd, maxi = S.maxi;
-                if (fb.k >= 0) { maxd = fb.d; maxi = c_i[C + fb.k]; }
+                long long src = S.best_k;            // the coarse maximum stands unless a fine step beats it
+                if (best.k >= 0) { maxd = best.d; maxi = c_i[C + best.k]; src = C + best.k; }
                 const int nd = S.nd;
                 det_start[T.ev_off + nd] = start;
                 det_maxi[T.ev_off + nd] = maxi;
                 det_d[T.ev_off + nd] = maxd;
                 win_det[T.ev_off + S.nw - 1] = 1;
+                S.seg_src = src;
+                S.seg_dst = T.ev_off + nd;
                 S.nd = nd + 1;
                 S.maxd = maxd; S.maxi = maxi;
                 S.fine = 0;
@@ -902,6 +1007,34 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
         }
         __syncthreads();
+        if (fine && seg_stats) {
+            // fused mode: the detected segment's statistics = the cache record of the split
+            // point (copied before the next scan's sweep, which comes after a barrier,
+            // overwrites the slots of this epoch)
+            const double* src = cache + S.seg_src * REC;
+            double* dst = seg_stats + S.seg_dst * REC;
+            for (int e = tid; e < REC; e += GW_TPB) dst[e] = src[e];
+        }
+    }
+    if (seg_stats && !S.abort) {
+        // fused mode: the tail segment [final start, turn end)
+        const int nd = S.nd;
+        if (nd >= T.ev_cap) {
+            if (tid == 0) atomicOr(err, 4);
+        } else {
+            double* dst = seg_stats + (T.ev_off + nd) * REC;
+            if ((long long)S.start >= n) {           // empty tail (an empty turn): all-zero moments
+                for (int e = tid; e < REC; e += GW_TPB) dst[e] = 0.0;
+            } else if (S.tail_in_lds) {
+                for (int e = tid; e < REC; e += GW_TPB) {
+                    int j, r;
+                    decode_entry(e, j, r);           // packed index -> (j, r), j <= r
+                    dst[e] = ldsEnd[tri_slot(r, j)];
+                }
+            } else {
+                gw_sweep_tail(fr, (long long)S.start, n, dst, err);
+            }
+        }
     }
     if (tid == 0) {
         n_win[turn] = S.nw;

@@ -355,21 +355,24 @@ __device__ __forceinline__ int find_problem(const int64_t* __restrict__ seg_off,
     return (int)lo;
 }
 
-constexpr int MX_WAVES = 8;
+constexpr int MX_WAVES = 4;
 
 // grid.x = total number of records; block g computes row a = g - seg_off[p] of
-// problem p: D[a][c] for c > a (and D[c][a] for variant 1), plus the diagonal /
-// lower-triangle initial values.  Each wave evaluates four partners per pass.
+// problem p = rec_prob[g]: D[a][c] for c > a (and D[c][a] for variant 1), plus the
+// diagonal / lower-triangle initial values.  Each wave evaluates four partners per pass.
+// Four waves per block, two blocks per CU: a block's start-up (staging its row's record,
+// a dependent chain of global loads) and its ragged end overlap with the other block's
+// eliminations -- with one eight-wave block per CU the SIMDs idled through both.
 template <bool TWO>
-__global__ __launch_bounds__(MX_WAVES * WAVE) void k_matrix(
-        const double* __restrict__ ex, const int64_t* __restrict__ seg_off, int64_t n_prob,
+__global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
+        const double* __restrict__ ex, const int64_t* __restrict__ seg_off, const int32_t* __restrict__ rec_prob,
         int variant, int kind, double lambdac,
         const double* __restrict__ ld, const double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
     __shared__ double ldsA[QREC];
     const int64_t g = blockIdx.x;
-    const int p = find_problem(seg_off, n_prob, g);
+    const int p = rec_prob[g];
     const int64_t off = seg_off[p];
     const int64_t N = seg_off[p + 1] - off;
     const int64_t ra = g - off;
@@ -764,19 +767,24 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
 // The same merge loop split over kernel launches ("wide" form): when there are
 // few problems (one long file, BASELINE.json configs 2 / 5) one workgroup per
 // problem leaves the chip idle and the loop is a serial chain of N - 1 rounds.
-// Here every round is three launches:
-//   k_ahc_update (a wave per row, all CUs)  finish the previous round's distances,
-//                write row / column sa, bring every row cache up to date (rows
-//                whose cached minimum was invalidated are rescanned on the spot);
-//   k_ahc_select (one workgroup per problem)  arg-min over the row caches, the
-//                stop decision, merge of the two records, partner list;
-//   k_ahc_pairs  (ceil(partners / 32) workgroups per problem)  the log dets.
-// The host enqueues N rounds back to back without reading anything: a problem
-// that stopped sets state.done and its later launches return at once.  No
-// inter-workgroup waiting anywhere, so no co-residency requirement.
+// Here a round is ONE launch, k_ahc_round, of ceil(partners / 31) workgroups per
+// problem:
+//   every workgroup  the log dets of the merged cluster with its 31 partners (and the
+//                merged cluster's own, which each of them needs), the finished distances,
+//                row / column sa of the matrix and the row caches of its partner rows
+//                (rows whose cached minimum was invalidated are rescanned on the spot);
+//   the workgroup that finishes last (an arrival ticket behind an agent-scope release;
+//                it takes an agent-scope acquire)  the next round's selection: row sa's
+//                own cache, arg-min over the row caches, the stop decision, the merge
+//                of the two records, the partner list.
+// Two small launches start the chain (row caches of the full matrix, first selection).
+// The host enqueues N - 1 rounds back to back without reading anything: a problem
+// that stopped sets state.done and its later launches return at once.  Nothing ever
+// waits for another workgroup, so there is no co-residency requirement.  Round 1's
+// three launches per merge (update / select / pairs) took 30 - 45 us per merge.
 // Arithmetic, tie-breaks and NaN rules are those of k_ahc.
 struct AhcState {
-    int32_t done, n_merges, nids, pad;
+    int32_t done, n_merges, nids, ticket;
     long long sa, sb;
     double nA, fmin;
 };
@@ -785,7 +793,7 @@ struct AhcState {
 // (k_ahc step 4; KL2 from the auxiliary records, 39 terms in index order)
 __device__ __forceinline__ double ahc_finish(int kind, double lambdac, const double* __restrict__ ex,
                                              const double* __restrict__ aux, const double* __restrict__ ldp,
-                                             const double* __restrict__ tp, int64_t off, long long sa,
+                                             double ldx, int64_t off, long long sa,
                                              long long c, double nA, double ldA) {
     if (kind == SPKD_KL2) {
         const double* a1 = aux + (off + sa) * AUX;
@@ -800,7 +808,7 @@ __device__ __forceinline__ double ahc_finish(int kind, double lambdac, const dou
         return 0.5 * t1 + 0.5 * t2;
     }
     const double nC = qr_count(ex + (off + c) * QREC);
-    return finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
+    return finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], ldx);
 }
 
 // wave-wide (min, first column, first NaN column) of one row; sub_col >= 0
@@ -840,68 +848,36 @@ __device__ __forceinline__ void ahc_scan_row(const double* __restrict__ row, lon
     }
 }
 
-// grid (ceil(n_max / 8), n_prob); wave w of block x owns row 8 x + w
-__global__ __launch_bounds__(AHC_TPB) void k_ahc_update(
-        int it, const double* __restrict__ ex, const int64_t* __restrict__ seg_off,
-        int variant, int kind, double lambdac,
-        const double* __restrict__ ld, const double* __restrict__ aux,
-        double* __restrict__ mat, const int64_t* __restrict__ mat_off,
-        int32_t* __restrict__ alive, const double* __restrict__ tmp,
-        double* __restrict__ rmin_all, int32_t* __restrict__ rcache_all,
-        const AhcState* __restrict__ state) {
+// grid (ceil(n_max / 8), n_prob); wave w of block x owns row 8 x + w: the row caches of
+// the full initial matrix, every record alive
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_init_rows(
+        const int64_t* __restrict__ seg_off, const double* __restrict__ mat,
+        const int64_t* __restrict__ mat_off, int32_t* __restrict__ alive,
+        double* __restrict__ rmin_all, int32_t* __restrict__ rcache_all) {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int p = blockIdx.y;
     const int64_t off = seg_off[p];
     const long long N = seg_off[p + 1] - off;
     const long long r = (long long)blockIdx.x * AHC_WAVES + wave;
     if (r >= N) return;
-    double* Dm = mat + mat_off[p];
+    const double* Dm = mat + mat_off[p];
     int32_t* al = alive + off;
-    const double* ldp = ld + off;
-    const double* tp = tmp + off;
     double* rmin = rmin_all + off;
     int32_t* rarg = rcache_all + 3 * off;
     int32_t* rnan = rarg + N;
     double mv;
     int mc, nc;
-    if (it == 0) {                    // first round: every row from the full matrix
-        ahc_scan_row(Dm + r * N, N, al, true, -1, 0.0, lane, mv, mc, nc);
-        if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; al[r] = 1; }
-        return;
-    }
-    const AhcState* S = state + p;
-    if (S->done || !al[r]) return;
-    const long long sa = S->sa, sb = S->sb;
-    const double nA = S->nA;
-    const double ldA = ldp[sa];
-    if (r == sa) return;             // row sa itself is rescanned by k_ahc_select
-    const double d = ahc_finish(kind, lambdac, ex, aux, ldp, tp, off, sa, r, nA, ldA);
-    const int ra = rarg[r], rn = rnan[r];
-    const double rm = rmin[r];
-    if (lane == 0) Dm[sa * N + r] = d;
-    if (variant == 1) {
-        if (lane == 0) Dm[r * N + sa] = d;
-        const bool nan_hit = (rn == sa || rn == sb);
-        if (ra == sa || ra == sb || nan_hit) {
-            if (!nan_hit && d < rm) {            // still (or now) the strict row minimum
-                if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
-            } else {
-                ahc_scan_row(Dm + r * N, N, al, false, sa, d, lane, mv, mc, nc);
-                if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
-            }
-        } else if (d != d) {
-            if (lane == 0 && (int)sa < rn) rnan[r] = (int)sa;
-        } else if (d < rm || (d == rm && (int)sa < ra)) {
-            if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
-        }
-    } else if (ra == sb || rn == sb) {           // column sa keeps its stale value (A-9)
-        ahc_scan_row(Dm + r * N, N, al, false, -1, 0.0, lane, mv, mc, nc);
-        if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
-    }
+    ahc_scan_row(Dm + r * N, N, al, true, -1, 0.0, lane, mv, mc, nc);
+    if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; al[r] = 1; }
 }
 
-__global__ __launch_bounds__(AHC_TPB) void k_ahc_select(
-        int it, double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+// The selection step of one problem, by one whole workgroup (AHC_TPB threads): with
+// it > 0 first the cache of the merged cluster's own row (this round's workgroups wrote
+// it) and the running statistics of variant 1 over the distances just evaluated; then
+// arg-min over the row caches (k_ahc step 1), the stop decision, the merge of the two
+// records and the partner list of the next round.
+__device__ __forceinline__ void ahc_select_body(
+        int it, int p, double* __restrict__ ex, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double threshold, double* __restrict__ aux,
         const double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         int32_t* __restrict__ alive, double* __restrict__ rmin_all,
@@ -916,7 +892,6 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_select(
     __shared__ int s_cnt[2];
     __shared__ int s_nids;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int p = blockIdx.x;
     const int64_t off = seg_off[p];
     const long long N = seg_off[p + 1] - off;
     int32_t* al = alive + off;
@@ -928,10 +903,9 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_select(
     const long long INF_IDX = 0x7fffffffffffffffLL;
     int n_merges = 0;
     if (it > 0) {
-        if (S->done) return;
         n_merges = S->n_merges;
-        // ---- 0. the merged cluster's own row (k_ahc_update wrote it): cache + the
-        // running statistics of variant 1 over the distances just evaluated
+        // ---- 0. the merged cluster's own row: cache + the running statistics of
+        // variant 1 over the distances just evaluated
         const long long psa = S->sa;
         const double* row = mat + mat_off[p] + psa * N;
         double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
@@ -1059,45 +1033,140 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_select(
     }
 }
 
+// the first selection of every problem (grid: n_prob)
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_select0(
+        double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        int variant, int kind, int max_spk, double threshold, double* __restrict__ aux,
+        const double* __restrict__ mat, const int64_t* __restrict__ mat_off,
+        int32_t* __restrict__ alive, double* __restrict__ rmin_all,
+        int32_t* __restrict__ rcache_all, int32_t* __restrict__ ids_all,
+        AhcState* __restrict__ state, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
+        double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
+        int* err) {
+    if (threadIdx.x == 0) state[blockIdx.x].ticket = 0;
+    ahc_select_body(0, blockIdx.x, ex, seg_off, variant, kind, max_spk, threshold, aux, mat, mat_off, alive,
+                    rmin_all, rcache_all, ids_all, state, out_a, out_b, out_d, stat_max, stat_min, err);
+}
+
+// partners per workgroup: every wave pass holds four matrices; the first slot of the
+// workgroup's first pass is the merged cluster itself
+constexpr int RND_PARTNERS = 4 * AHC_WAVES - 1;
+
+// one merge round; grid (ceil((n_max - 1) / RND_PARTNERS), n_prob)
 template <bool TWO>
-__global__ __launch_bounds__(AHC_TPB) void k_ahc_pairs(
-        const double* __restrict__ ex, const int64_t* __restrict__ seg_off, int kind,
-        double* __restrict__ ld, double* __restrict__ tmp, const int32_t* __restrict__ ids_all,
-        const AhcState* __restrict__ state, int* err) {
+__global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
+        int it, double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        int variant, int kind, int max_spk, double lambdac, double threshold,
+        double* __restrict__ ld, double* __restrict__ aux,
+        double* __restrict__ mat, const int64_t* __restrict__ mat_off,
+        int32_t* __restrict__ alive, double* __restrict__ rmin_all,
+        int32_t* __restrict__ rcache_all, int32_t* __restrict__ ids_all,
+        AhcState* __restrict__ state, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
+        double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
+        int* err) {
     __shared__ double ldsA[QREC];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    __shared__ double s_ldx[4 * AHC_WAVES];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
     const int p = blockIdx.y;
-    const AhcState* S = state + p;
+    AhcState* S = state + p;
     if (S->done) return;
-    const int nids = S->nids;
-    if ((int)blockIdx.x * 4 * AHC_WAVES >= nids) return;
+    const int nids = S->nids;                       // 1 + partners
+    const int nb = nids > 1 ? (nids - 1 + RND_PARTNERS - 1) / RND_PARTNERS : 1;
+    if ((int)blockIdx.x >= nb) return;
     const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
     const int32_t* ids = ids_all + off;
-    const long long sa = S->sa;
+    const long long sa = S->sa, sb = S->sb;
+    const double nA = S->nA;
     const double* A = ex + (off + sa) * QREC;
-    for (int e = tid; e < QREC; e += AHC_TPB) ldsA[e] = A[e];
-    __syncthreads();
-    const double nA = ldsA[QREC_COUNT_AT];
-    const int base = ((int)blockIdx.x * AHC_WAVES + wave) * 4;
-    if (base >= nids) return;
-    const double* recs[4];
-    bool selfs[4];
+    double* Dm = mat + mat_off[p];
+    int32_t* al = alive + off;
+    double* ldp = ld + off;
+    double* rmin = rmin_all + off;
+    int32_t* rarg = rcache_all + 3 * off;
+    int32_t* rnan = rarg + N;
+    // this workgroup's items: item 0 = the merged cluster itself, item j >= 1 = partner
+    // ids[first + j - 1]
+    const int first = 1 + (int)blockIdx.x * RND_PARTNERS;
+    const int mine = nids - first < RND_PARTNERS ? nids - first : RND_PARTNERS;     // partners here (>= 0)
+    if (kind != SPKD_KL2) {
+        for (int e = tid; e < QREC; e += AHC_TPB) ldsA[e] = A[e];
+        __syncthreads();
+        const int base = 4 * wave;                  // items base .. base + 3 of this wave
+        if (base <= mine) {
+            const double* recs[4];
+            bool selfs[4];
+            int item[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        int k = base + mi;
-        k = k < nids ? k : nids - 1;
-        recs[mi] = ex + (off + ids[k]) * QREC;
-        selfs[mi] = (k == 0);
+            for (int mi = 0; mi < 4; ++mi) {
+                int j = base + mi;
+                j = j <= mine ? j : mine;           // clamp to the last valid item (item 0 exists always)
+                item[mi] = j;
+                recs[mi] = j == 0 ? A : ex + (off + ids[first + j - 1]) * QREC;
+                selfs[mi] = (j == 0);
+            }
+            int j = base + L.m;
+            const bool valid = j <= mine;
+            j = valid ? j : mine;
+            const double* C = j == 0 ? A : ex + (off + ids[first + j - 1]) * QREC;
+            const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, j == 0, L, recs, selfs, err);
+            if (valid && L.t == 0) s_ldx[j] = v;
+        }
+        __syncthreads();
     }
-    int k = base + L.m;
-    const bool valid = k < nids;
-    k = valid ? k : nids - 1;
-    const int32_t slot = ids[k];
-    const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
-    if (valid && L.t == 0) {
-        if (k == 0) ld[off + sa] = v; else tmp[off + slot] = v;
+    const double ldA = kind == SPKD_KL2 ? 0.0 : s_ldx[0];
+    if (kind != SPKD_KL2 && blockIdx.x == 0 && tid == 0) ldp[sa] = ldA;      // the merged cluster's cached term
+    // ---- finish this workgroup's distances, row / column sa, the partner rows' caches
+    // (a wave per row: a row whose cached minimum was invalidated is rescanned at once)
+    for (int j = 1 + wave; j <= mine; j += AHC_WAVES) {
+        const long long r = ids[first + j - 1];
+        const double d = ahc_finish(kind, lambdac, ex, aux, ldp, kind == SPKD_KL2 ? 0.0 : s_ldx[j], off, sa, r, nA, ldA);
+        const int ra = rarg[r], rn = rnan[r];
+        const double rm = rmin[r];
+        double mv;
+        int mc, nc;
+        if (lane == 0) Dm[sa * N + r] = d;
+        if (variant == 1) {
+            if (lane == 0) Dm[r * N + sa] = d;
+            const bool nan_hit = (rn == sa || rn == sb);
+            if (ra == sa || ra == sb || nan_hit) {
+                if (!nan_hit && d < rm) {            // still (or now) the strict row minimum
+                    if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
+                } else {
+                    ahc_scan_row(Dm + r * N, N, al, false, sa, d, lane, mv, mc, nc);
+                    if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
+                }
+            } else if (d != d) {
+                if (lane == 0 && (int)sa < rn) rnan[r] = (int)sa;
+            } else if (d < rm || (d == rm && (int)sa < ra)) {
+                if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
+            }
+        } else if (ra == sb || rn == sb) {           // column sa keeps its stale value (A-9)
+            ahc_scan_row(Dm + r * N, N, al, false, -1, 0.0, lane, mv, mc, nc);
+            if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
+        }
     }
+    // ---- arrival: everything this workgroup wrote is released at agent scope before its
+    // ticket; the last arriver acquires and runs the next selection
+    __syncthreads();                                 // (waits for every wave's stores)
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = atomicAdd(&S->ticket, 1);
+        const int last = (t == nb - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            S->ticket = 0;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    ahc_select_body(it, p, ex, seg_off, variant, kind, max_spk, threshold, aux, mat, mat_off, alive,
+                    rmin_all, rcache_all, ids_all, state, out_a, out_b, out_d, stat_max, stat_min, err);
 }
 
 __global__ __launch_bounds__(AHC_TPB) void k_ahc_final(

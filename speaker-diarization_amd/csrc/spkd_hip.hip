@@ -20,7 +20,7 @@
 using namespace spkd;
 
 namespace {
-constexpr int N_SLOTS = 24;
+constexpr int N_SLOTS = 25;
 }
 
 struct spkd_ctx {
@@ -121,7 +121,7 @@ spkd_status end_call(spkd_ctx* c) {
 enum {
     S_CHUNKS = 0, S_SETOFF, S_PARTIAL, S_IDXA, S_IDXB, S_TERMS, S_TURNS, S_SNAP, S_CAND,
     S_EV_I32A, S_EV_I32B, S_EV_D0, S_EV_D1, S_EV_D2, S_EV_D3, S_EV_D4, S_LOG,
-    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF
+    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB
 };
 
 }  // namespace
@@ -318,7 +318,7 @@ struct AhcBuffers {
 
 spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
                         int variant, int kind, double lambdac, AhcBuffers& B, int64_t& n_total,
-                        std::vector<int64_t>& offs) {     // offs must outlive the stream work
+                        std::vector<int64_t>& offs, std::vector<int32_t>& prob_of) {     // both must outlive the stream work
     n_total = h_seg_off[n_prob];
     offs.clear();                                    // seg_off | mat_off
     offs.insert(offs.end(), h_seg_off, h_seg_off + n_prob + 1);
@@ -330,9 +330,14 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
         cells += n * n;
     }
     offs.push_back(cells);
+    prob_of.assign((size_t)n_total, 0);              // record -> its problem
+    for (int64_t p = 0; p < n_prob; ++p)
+        for (int64_t r = h_seg_off[p]; r < h_seg_off[p + 1]; ++r) prob_of[(size_t)r] = (int32_t)p;
     int64_t* d_offs = nullptr;
+    int32_t* d_prob = nullptr;
     spkd_status st;
     if ((st = upload(c, S_AHC_OFF, offs, &d_offs)) != SPKD_OK) return st;
+    if ((st = upload(c, S_AHC_PROB, prob_of, &d_prob)) != SPKD_OK) return st;
     B.seg_off = d_offs;
     B.mat_off = d_offs + n_prob + 1;
     void* p = nullptr;
@@ -360,7 +365,7 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
         auto kmat = kind == SPKD_GLR ? k_matrix<true> : k_matrix<false>;   // GLR has a second rank-one term
         TIMED(c, SPKD_T_MATRIX,
               hipLaunchKernelGGL(kmat, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
-                                 (const double*)B.ex, (const int64_t*)B.seg_off, n_prob, variant, kind, lambdac,
+                                 (const double*)B.ex, (const int64_t*)B.seg_off, (const int32_t*)d_prob, variant, kind, lambdac,
                                  (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
                                  B.smax, B.smin, c->d_err));
     }
@@ -388,7 +393,8 @@ spkd_status spkd_distance_matrix(spkd_ctx* c, int kind, double lambdac, const do
     AhcBuffers B;
     int64_t n_total = 0;
     std::vector<int64_t> offs;
-    if ((st = ahc_prepare(c, d_stats, seg_off, 1, 1, kind, lambdac, B, n_total, offs)) != SPKD_OK) return st;
+    std::vector<int32_t> prob_of;
+    if ((st = ahc_prepare(c, d_stats, seg_off, 1, 1, kind, lambdac, B, n_total, offs, prob_of)) != SPKD_OK) return st;
     HIPCHK(c, hipMemcpyAsync(d_matrix, B.mat, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return end_call(c);
 }
@@ -412,7 +418,8 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     int64_t n_total = 0;
     // ahc_prepare expands the records into a private working copy (merged in place)
     std::vector<int64_t> offs;
-    if ((st = ahc_prepare(c, d_stats, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs)) != SPKD_OK) return st;
+    std::vector<int32_t> prob_of;
+    if ((st = ahc_prepare(c, d_stats, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs, prob_of)) != SPKD_OK) return st;
     int64_t n_max = 0;
     for (int64_t p = 0; p < n_prob; ++p) n_max = std::max<int64_t>(n_max, h_seg_off[p + 1] - h_seg_off[p]);
     if (n_max > AHC_MAX_N) return fail(c, SPKD_EINVAL, "clustering problem larger than 65536 records");
@@ -449,27 +456,25 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
                                  P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
                                  d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
     } else {
-        auto kpairs = P->kind == SPKD_GLR ? k_ahc_pairs<true> : k_ahc_pairs<false>;
+        auto kround = P->kind == SPKD_GLR ? k_ahc_round<true> : k_ahc_round<false>;
         (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
         const unsigned row_blocks = (unsigned)((n_max + AHC_WAVES - 1) / AHC_WAVES);
-        for (int64_t it = 0; it < n_max; ++it) {
-            hipLaunchKernelGGL(k_ahc_update, dim3(row_blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
-                               (int)it, (const double*)B.ex, (const int64_t*)B.seg_off, P->variant, P->kind,
-                               P->lambdac, (const double*)B.ld, (const double*)B.aux, B.mat,
-                               (const int64_t*)B.mat_off, d_alive, (const double*)d_tmp, d_rmin, d_rcache,
-                               (const AhcState*)d_state);
-            hipLaunchKernelGGL(k_ahc_select, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+        hipLaunchKernelGGL(k_ahc_init_rows, dim3(row_blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                           (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off, d_alive,
+                           d_rmin, d_rcache);
+        hipLaunchKernelGGL(k_ahc_select0, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                           B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->threshold, B.aux,
+                           (const double*)B.mat, (const int64_t*)B.mat_off, d_alive, d_rmin, d_rcache, d_ids,
+                           d_state, d_a, d_b, d_merge_d, B.smax, B.smin, c->d_err);
+        // round `it` finishes merge `it` (its distances, row caches) and selects merge it + 1;
+        // after merge `it` a problem of n records has n - it clusters, i.e. n - it - 1 partners
+        for (int64_t it = 1; it < n_max; ++it) {
+            const int64_t partners = n_max - it - 1;
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + RND_PARTNERS - 1) / RND_PARTNERS);
+            hipLaunchKernelGGL(kround, dim3(blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
                                (int)it, B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk,
-                               P->threshold, B.aux, (const double*)B.mat, (const int64_t*)B.mat_off, d_alive,
-                               d_rmin, d_rcache, d_ids, d_state, d_a, d_b, d_merge_d, B.smax, B.smin,
-                               c->d_err);
-            if (it + 1 < n_max && P->kind != SPKD_KL2) {
-                const int64_t partners = n_max - it - 1;       // alive clusters after merge `it`
-                const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + 4 * AHC_WAVES - 1) / (4 * AHC_WAVES));
-                hipLaunchKernelGGL(kpairs, dim3(blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
-                                   (const double*)B.ex, (const int64_t*)B.seg_off, P->kind, B.ld, d_tmp,
-                                   (const int32_t*)d_ids, (const AhcState*)d_state, c->d_err);
-            }
+                               P->lambdac, P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive,
+                               d_rmin, d_rcache, d_ids, d_state, d_a, d_b, d_merge_d, B.smax, B.smin, c->d_err);
         }
         hipLaunchKernelGGL(k_ahc_final, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
                            (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off,
@@ -554,20 +559,12 @@ spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const 
 }
 }  // namespace
 
-spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+namespace {
+spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
                     const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
-                    int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det, double* h_det_start,
-                    double* h_det_maxi, double* h_det_d, double* h_final_start, spkd_cand_log* h_log,
-                    int64_t log_cap, int64_t* h_log_count) {
-    return spkd_gw_ex(c, d_frames, n_frames, hb, he, n_turns, P, h_ev_off, 1, h_n_win, h_win_maxd, h_win_det,
-                      h_det_start, h_det_maxi, h_det_d, h_final_start, h_log, log_cap, h_log_count);
-}
-
-spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
-                       const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
-                       int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
-                       double* h_det_start, double* h_det_maxi, double* h_det_d, double* h_final_start,
-                       spkd_cand_log* h_log, int64_t log_cap, int64_t* h_log_count) {
+                    int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
+                    double* h_det_start, double* h_det_maxi, double* h_det_d, double* h_final_start,
+                    double* d_seg_stats, spkd_cand_log* h_log, int64_t log_cap, int64_t* h_log_count) {
     if (!c || !P || n_turns < 0) return SPKD_EINVAL;
     if (h_log_count) *h_log_count = 0;
     if (n_turns == 0) return SPKD_OK;
@@ -577,6 +574,7 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
     if (P->kind < 0 || P->kind > 2) return fail(c, SPKD_EINVAL, "gw: bad kind");
     if (!(P->rate >= 10.0) || !(P->winsize >= 1.0) || !(P->winstep >= 1.0))
         return fail(c, SPKD_EINVAL, "gw: rate >= 10, winsize >= 1 frame and winstep >= 1 frame required");
+    if (log_cap < 0 || (log_cap > 0 && !h_log)) return fail(c, SPKD_EINVAL, "gw: log capacity without a log buffer");
     if (!c->gw_lds_ok) return fail(c, SPKD_EHIP, "gw: the kernel's dynamic LDS size was not admitted on this device");
     std::vector<TurnDesc> turns;
     int64_t n_snap, n_cand;
@@ -588,11 +586,12 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
     if ((st = begin_call(c)) != SPKD_OK) return st;
     const int64_t n_ev = h_ev_off[n_turns];
     TurnDesc* d_turns = nullptr;
-    void *d_snap, *d_cand, *d_i32a, *d_i32b, *d_d0, *d_d1, *d_d2, *d_d3, *d_d4, *d_log;
+    void *d_snap = nullptr, *d_cand = nullptr, *d_i32a = nullptr, *d_i32b = nullptr, *d_d0 = nullptr, *d_d1 = nullptr,
+         *d_d2 = nullptr, *d_d3 = nullptr, *d_d4 = nullptr, *d_log = nullptr;
     if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
-    // one tri record (running moment sums at the split point) per candidate slot
+    // one packed record (running moment sums at the split point) per candidate slot
     (void)n_snap;
-    if ((st = scratch(c, S_SNAP, (size_t)n_cand * TREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_SNAP, (size_t)n_cand * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
     if ((st = scratch(c, S_CAND, (size_t)n_cand * 4 * sizeof(double), &d_cand)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32A, (size_t)n_turns * sizeof(int32_t), &d_i32a)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32B, (size_t)n_ev * sizeof(int32_t), &d_i32b)) != SPKD_OK) return st;
@@ -602,12 +601,16 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
     if ((st = scratch(c, S_EV_D3, (size_t)n_ev * sizeof(double), &d_d3)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_D4, (size_t)n_turns * sizeof(double), &d_d4)) != SPKD_OK) return st;
     if ((st = scratch(c, S_LOG, (size_t)std::max<int64_t>(log_cap, 1) * sizeof(spkd_cand_log), &d_log)) != SPKD_OK) return st;
+    // every pointer the kernel dereferences (a null one would be a GPU memory fault, not a status)
+    if (!d_turns || !d_snap || !d_cand || !d_i32a || !d_i32b || !d_d0 || !d_d1 || !d_d2 || !d_d3 || !d_d4 ||
+        !d_log || !c->d_counter || !c->d_err)
+        return fail(c, SPKD_EHIP, "gw: a device scratch buffer is missing");
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
     TIMED(c, SPKD_T_GW,
           hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_BYTES, c->stream,
                              d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
                              (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
-                             (double*)d_d3, (double*)d_d4, (spkd_cand_log*)d_log, (long long)log_cap,
+                             (double*)d_d3, (double*)d_d4, d_seg_stats, (spkd_cand_log*)d_log, (long long)log_cap,
                              c->d_counter, c->d_err));
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt = 0;
@@ -628,6 +631,73 @@ spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, con
     if (st == SPKD_OK && (int64_t)cnt > log_cap && h_log)
         return fail(c, SPKD_EOVERFLOW, "candidate log too small");
     return st;
+}
+}  // namespace
+
+spkd_status spkd_gw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+                    const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
+                    int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det, double* h_det_start,
+                    double* h_det_maxi, double* h_det_d, double* h_final_start, spkd_cand_log* h_log,
+                    int64_t log_cap, int64_t* h_log_count) {
+    return gw_impl(c, d_frames, n_frames, hb, he, n_turns, P, h_ev_off, 1, h_n_win, h_win_maxd, h_win_det,
+                   h_det_start, h_det_maxi, h_det_d, h_final_start, nullptr, h_log, log_cap, h_log_count);
+}
+
+spkd_status spkd_gw_ex(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+                       const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
+                       int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
+                       double* h_det_start, double* h_det_maxi, double* h_det_d, double* h_final_start,
+                       spkd_cand_log* h_log, int64_t log_cap, int64_t* h_log_count) {
+    return gw_impl(c, d_frames, n_frames, hb, he, n_turns, P, h_ev_off, check_capacity, h_n_win, h_win_maxd,
+                   h_win_det, h_det_start, h_det_maxi, h_det_d, h_final_start, nullptr, h_log, log_cap,
+                   h_log_count);
+}
+
+spkd_status spkd_gw_fused(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
+                          const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
+                          int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
+                          double* h_det_start, double* h_det_maxi, double* h_det_d, double* h_final_start,
+                          double* d_seg_stats, spkd_cand_log* h_log, int64_t log_cap, int64_t* h_log_count) {
+    if (c && !d_seg_stats) return fail(c, SPKD_EINVAL, "gw_fused: null statistics buffer");
+    return gw_impl(c, d_frames, n_frames, hb, he, n_turns, P, h_ev_off, check_capacity, h_n_win, h_win_maxd,
+                   h_win_det, h_det_start, h_det_maxi, h_det_d, h_final_start, d_seg_stats, h_log, log_cap,
+                   h_log_count);
+}
+
+// records d_dst[dst[i]] = d_src[src[i]] (dst = NULL: i)
+namespace {
+__global__ __launch_bounds__(256) void k_gather_records(const double* __restrict__ src, const int64_t* __restrict__ si,
+                                                        const int64_t* __restrict__ di, int64_t n,
+                                                        double* __restrict__ dst) {
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const double2* s = reinterpret_cast<const double2*>(src + si[i] * REC);
+    double2* d = reinterpret_cast<double2*>(dst + (di ? di[i] : i) * REC);
+    for (int e = threadIdx.x; e < REC / 2; e += 256) d[e] = s[e];
+}
+}  // namespace
+
+spkd_status spkd_gather_stats(spkd_ctx* c, const double* d_src, int64_t n_src, const int64_t* h_src_index,
+                              const int64_t* h_dst_index, int64_t n, int64_t n_dst, double* d_dst) {
+    if (!c || n < 0) return SPKD_EINVAL;
+    if (n == 0) return SPKD_OK;
+    if (!d_src || !h_src_index || !d_dst) return fail(c, SPKD_EINVAL, "null argument");
+    for (int64_t i = 0; i < n; ++i) {
+        if (h_src_index[i] < 0 || h_src_index[i] >= n_src) return fail(c, SPKD_EINVAL, "gather: source index out of range");
+        const int64_t d = h_dst_index ? h_dst_index[i] : i;
+        if (d < 0 || d >= n_dst) return fail(c, SPKD_EINVAL, "gather: destination index out of range");
+    }
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    std::vector<int64_t> idx(h_src_index, h_src_index + n);
+    if (h_dst_index) idx.insert(idx.end(), h_dst_index, h_dst_index + n);
+    int64_t* d_idx = nullptr;
+    if ((st = upload(c, S_IDXA, idx, &d_idx)) != SPKD_OK) return st;
+    hipLaunchKernelGGL(k_gather_records, dim3((unsigned)n), dim3(256), 0, c->stream, d_src,
+                       (const int64_t*)d_idx, h_dst_index ? (const int64_t*)(d_idx + n) : (const int64_t*)nullptr,
+                       n, d_dst);
+    HIPCHK(c, hipGetLastError());
+    return end_call(c);       // (idx must outlive the copy: end_call waits for the stream)
 }
 
 spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,

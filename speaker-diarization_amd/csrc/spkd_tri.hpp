@@ -37,11 +37,15 @@ __device__ __forceinline__ void fmac_bcast16(double& acc, double src, double m) 
 
 // broadcast with its own wait states (the source may have been written by the asm
 // FMA just before, which the compiler does not see as a VALU write)
-template <int T>
+template <int T, bool NOP = true>
 __device__ __forceinline__ double bcast16_nop(double v) {
     double r;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "=v"(r) : "v"(v), "n"(T));
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "=v"(r) : "v"(v), "n"(T));
+    else
+        asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "=v"(r) : "v"(v), "n"(T));
     return r;
 }
 
@@ -69,31 +73,39 @@ struct TriCol {
     }
 };
 
+// Step K.  The pivot a[K][K] was last written by the first column of step K - 1; the
+// remaining columns of that step (two instructions or more while K <= 36) separate that
+// write from the broadcast below, so only the first step (its source comes straight out
+// of the formation code) and the last two carry wait states of their own.
+// The smallest pivot is tracked instead of a per-step test: a pivot that is not a
+// positive finite number shows as pmin <= 0 or as a determinant that is NaN or infinite
+// (v_min_f64 drops a NaN operand, the product keeps it).
 template <int K>
 struct TriStep {
-    static __device__ __forceinline__ void run(QuadRows& q, double& det, bool& ok) {
+    static __device__ __forceinline__ void run(QuadRows& q, double& det, double& pmin) {
         if constexpr (K < D) {
             constexpr int S = K / QL, T = K % QL;
-            const double piv = bcast16_nop<T>(q.r[S][K]);
-            ok = ok && (piv > 0.0) && (piv < __builtin_huge_val());
+            const double piv = bcast16_nop<T, (K == 0 || K > 36)>(q.r[S][K]);
+            asm("v_min_f64 %0, %1, %2" : "=v"(pmin) : "v"(pmin), "v"(piv));    // (fmin() adds a canonicalisation)
             det *= piv;
             const double inv = fast_recip(piv);
             double l[QS];
 #pragma unroll
             for (int s = 0; s < QS; ++s) l[s] = (s >= S) ? -(q.r[s][K] * inv) : 0.0;
             TriCol<K, K + 1>::run(q, l);
-            TriStep<K + 1>::run(q, det, ok);
+            TriStep<K + 1>::run(q, det, pmin);
         }
     }
 };
 
 // det (per DPP row) of four symmetric matrices given by their lower triangles.
+// false: some pivot was not a positive finite number (or the product left the range).
 __device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out) {
     double det = 1.0;
-    bool ok = true;
-    TriStep<0>::run(q, det, ok);
+    double pmin = __builtin_huge_val();
+    TriStep<0>::run(q, det, pmin);
     det_out = det;
-    return ok;
+    return (pmin > 0.0) && (det == det) && (det < __builtin_huge_val());
 }
 
 // q[s][J] += c[s] * v_J for the lower-triangle columns (v distributed like the rows)

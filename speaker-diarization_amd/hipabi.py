@@ -19,7 +19,7 @@ DIM = 39
 EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
            'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
-           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex',
+           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
            'spkd_labels_from_merges', 'spkd_labels_from_merges_batch']
 
@@ -89,6 +89,9 @@ def load_library(path=None):
                             vp, i64, P(i64)]
     lib.spkd_gw_ex.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, C.c_int, vp, vp, vp, vp, vp, vp,
                                vp, vp, i64, P(i64)]
+    lib.spkd_gw_fused.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, C.c_int, vp, vp, vp, vp, vp, vp,
+                                  vp, vp, vp, i64, P(i64)]
+    lib.spkd_gather_stats.argtypes = [vp, vp, i64, vp, vp, i64, i64, vp]
     lib.spkd_sw_window_count.argtypes = [i64, dbl, dbl]
     lib.spkd_sw_window_count.restype = i64
     lib.spkd_sw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp]
@@ -244,12 +247,24 @@ class Context(object):
             arr = cache[name] = np.empty(max(n, 1), dtype=dtype)
         return arr[:n]
 
-    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096, tight=False, reuse=False):
+    def gather_stats(self, d_src, n_src, src_index, d_dst, n_dst, dst_index=None):
+        """d_dst[dst_index[i]] = d_src[src_index[i]] (whole statistics records)."""
+        si = np.ascontiguousarray(src_index, dtype=np.int64)
+        di = None if dst_index is None else np.ascontiguousarray(dst_index, dtype=np.int64)
+        self.check(self.lib.spkd_gather_stats(self.h, C.c_void_p(d_src), n_src, _ptr(si),
+                                              None if di is None else _ptr(di), len(si), n_dst,
+                                              C.c_void_p(d_dst)))
+
+    def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096, tight=False, reuse=False,
+           seg_stats=None):
         """tight=True sizes the event arrays for the typical case (a quarter of the
         guaranteed bound) and transparently repeats the call with the full bound if
         the device reports an overflow -- four times less data to allocate and copy.
         reuse=True returns views of per-context buffers: valid until the next gw call
-        on this context."""
+        on this context.
+        seg_stats: a callable n_records -> device pointer; turns the call into the fused
+        form (spkd_gw_fused): the statistics record of segment j of turn t is left at
+        record off[t] + j of that buffer."""
         b = np.ascontiguousarray(begins, dtype=np.int64)
         e = np.ascontiguousarray(ends, dtype=np.int64)
         nt = len(b)
@@ -274,11 +289,19 @@ class Context(object):
             final_start = mk('final_start', nt, np.float64)
             log = (CandLog * max(log_cap, 1))()
             cnt = C.c_int64(0)
-            st = self.lib.spkd_gw_ex(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
-                                     C.byref(params), _ptr(off), 0 if tight else 1, _ptr(n_win),
-                                     _ptr(win_maxd), _ptr(win_det), _ptr(det_start), _ptr(det_maxi),
-                                     _ptr(det_d), _ptr(final_start), C.cast(log, C.c_void_p), log_cap,
-                                     C.byref(cnt))
+            if seg_stats is None:
+                st = self.lib.spkd_gw_ex(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
+                                         C.byref(params), _ptr(off), 0 if tight else 1, _ptr(n_win),
+                                         _ptr(win_maxd), _ptr(win_det), _ptr(det_start), _ptr(det_maxi),
+                                         _ptr(det_d), _ptr(final_start), C.cast(log, C.c_void_p), log_cap,
+                                         C.byref(cnt))
+            else:
+                d_seg = seg_stats(nev)
+                st = self.lib.spkd_gw_fused(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
+                                            C.byref(params), _ptr(off), 0 if tight else 1, _ptr(n_win),
+                                            _ptr(win_maxd), _ptr(win_det), _ptr(det_start), _ptr(det_maxi),
+                                            _ptr(det_d), _ptr(final_start), C.c_void_p(d_seg),
+                                            C.cast(log, C.c_void_p), log_cap, C.byref(cnt))
             if st == SPKD_EOVERFLOW and cnt.value > log_cap:
                 log_cap = int(cnt.value) + 16      # the run is deterministic: retry with room
                 continue
@@ -287,7 +310,7 @@ class Context(object):
                 continue
             self.check(st, allow=(SPKD_ENONFINITE,))
             break
-        return dict(status=st, off=off, n_win=n_win, win_maxd=win_maxd, win_det=win_det,
+        return dict(status=st, off=off, n_ev=nev, n_win=n_win, win_maxd=win_maxd, win_det=win_det,
                     det_start=det_start, det_maxi=det_maxi, det_d=det_d, final_start=final_start,
                     log=log, log_count=min(int(cnt.value), log_cap))
 

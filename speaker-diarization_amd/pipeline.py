@@ -32,14 +32,27 @@ class BatchFile(object):
         self.vad = [(float(s), float(e)) for (s, e) in vad]
 
 
+class FusedStats(object):
+    """What the fused change detector leaves for the clustering stage: per recipe line
+    (same order as the concatenated per-file segment lists) the record index of its
+    statistics in the device buffer and the absolute frame range those statistics
+    cover."""
+
+    def __init__(self, d_buf, n_buf, index, begin, end):
+        self.d_buf, self.n_buf, self.index, self.begin, self.end = d_buf, n_buf, index, begin, end
+
+
 def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, timings=None,
-                        text_contract=True):
+                        text_contract=True, fused=None):
     """Returns, per file, the list of (start_s, end_s) the change-detection recipe
     would contain (already passed through the 12-digit text round trip).
     text_contract=False is the opt-in fused mode of SURVEY.md §8(f) row 4: the times go
     to the clustering stage as the doubles they are, without being printed and re-read
     (A-2) -- NOT the reference's semantics: a boundary within 1e-12 relative of a frame
-    edge can land one frame away."""
+    edge can land one frame away.
+    fused: a list; when given, the detector also leaves the statistics record of every
+    segment on the device (spkd_gw_fused) and a FusedStats is appended to the list, so that
+    cluster_batch does not read the frames a second time."""
     rate = float(rate)
     _t0 = time.perf_counter()
     nturn = [len(f.vad) for f in files]
@@ -57,7 +70,15 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
                         float(np.floor(cd['winsize_s'] * rate)), float(np.floor(cd['winstep_s'] * rate)),
                         float(np.floor(rate * cd['deltaws_s'])), rate)
     _t1 = time.perf_counter()
-    r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096, tight=True, reuse=True)
+    seg_buf = {}
+
+    def seg_alloc(n_rec):
+        seg_buf['n'] = n_rec
+        seg_buf['p'] = ctx.dev_scratch('fused_segment_stats', max(n_rec, 1) * hipabi.REC * 8)
+        return seg_buf['p']
+
+    r = ctx.gw(d_frames, total_frames, tb, te, p, log_cap=4096, tight=True, reuse=True,
+               seg_stats=seg_alloc if fused is not None else None)
     _t2 = time.perf_counter()
     if timings is not None:
         timings.setdefault('gw', []).append(ctx.last_ms('gw'))
@@ -89,6 +110,16 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     t1[~is_tail] = d_end / rate + ls[det_turn]
     t0[is_tail] = r['final_start'] / rate + ls
     t1[is_tail] = ((le - ls) * rate) / rate + ls
+    if fused is not None:
+        # the frames each record covers: [int(start), int(start + maxi)) of the turn for a
+        # detection, [int(final start), turn end) for the tail
+        fb = np.empty(len(line_turn), dtype=np.int64); fe = np.empty(len(line_turn), dtype=np.int64)
+        fb[~is_tail] = tb[det_turn] + d_start.astype(np.int64)
+        fe[~is_tail] = tb[det_turn] + d_end.astype(np.int64)
+        fb[is_tail] = tb + r['final_start'].astype(np.int64)
+        fe[is_tail] = te
+        index = off[line_turn] + (np.arange(len(line_turn)) - lfirst[line_turn])
+        fused.append(FusedStats(seg_buf['p'], seg_buf['n'], index, fb, fe))
     rt = np.stack([t0, t1], axis=1)
     if text_contract:
         rt = hipabi.py2_roundtrip(rt.ravel()).reshape(-1, 2)
@@ -104,13 +135,17 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
 
 
 def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=DIA2_CL, timings=None,
-                  want_merges=False):
+                  want_merges=False, fused=None):
     """segments: per file, array [(start_s, end_s)] as the clustering script parses
     them.  Returns per file (labels[int array, 1-based, per segment in input
-    order], merges[(a, b, d)])."""
+    order], merges[(a, b, d)]).
+    fused: the FusedStats of change_detect_batch for exactly these segments: the records
+    of the segments whose frame range (as computed here, from the times) equals the range
+    the detector summed are gathered from its buffer; only the others -- a boundary the
+    12-digit text round trip moved across a frame edge -- are computed from the frames."""
     rate = float(rate)
     # files without any segment are not clustering problems (spkd_ahc rejects empty ones)
-    if any(len(sg) == 0 for sg in segments):
+    if fused is None and any(len(sg) == 0 for sg in segments):
         keep = [i for i, sg in enumerate(segments) if len(sg) > 0]
         out = [(np.zeros(0, dtype=np.int32), [] if want_merges else None) for _ in files]
         if keep:
@@ -133,13 +168,27 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
     b, e = foff + a0, foff + a1
     d_stats = ctx.dev_scratch('segment_stats', max(n, 1) * hipabi.REC * 8)
     _t1 = time.perf_counter()
-    ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
+    if fused is None:
+        ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
+        redo = np.arange(n)
+    else:
+        same = (fused.begin == b) & (fused.end == e)
+        keep = np.nonzero(same)[0]
+        redo = np.nonzero(~same)[0]
+        ctx.gather_stats(fused.d_buf, fused.n_buf, fused.index[keep], d_stats, n, keep)
+        if len(redo):
+            d_tmp = ctx.dev_scratch('segment_stats_redo', len(redo) * hipabi.REC * 8)
+            ctx.set_stats(d_frames, total_frames, b[redo], e[redo], np.arange(len(redo), dtype=np.int32),
+                          len(redo), d_tmp)
+            ctx.gather_stats(d_tmp, len(redo), np.arange(len(redo)), d_stats, n, redo)
     _t2 = time.perf_counter()
     if timings is not None:
-        timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
-        timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
-        timings['stats_frames'] = int((e - b).sum())
+        if len(redo):
+            timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
+            timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
+        timings['stats_frames'] = int((e[redo] - b[redo]).sum())
         timings['stats_sets'] = n
+        timings['stats_recomputed'] = int(len(redo))
     p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], cl.get('path', 0),
                          cl['lambdac'], cl['threshold'])
     r = ctx.ahc(d_stats, seg_off, p)
@@ -173,11 +222,33 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
 
 
 def diarize_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_CD, cl=DIA2_CL, timings=None,
-                  text_contract=True):
+                  text_contract=True, fused=False):
     """CD (gw/BIC) + CL (hi/BIC) for a batch; returns per file an array of rows
-    [start_s, end_s, speaker] in recipe order."""
-    segs = change_detect_batch(ctx, d_frames, total_frames, files, rate, cd, timings, text_contract)
-    res = cluster_batch(ctx, d_frames, total_frames, files, segs, rate, cl, timings)
+    [start_s, end_s, speaker] in recipe order.
+    fused=True: the frames are read once -- the change detector leaves every segment's
+    statistics record for the clustering stage (segments and labels are those of the
+    two-pass form; a record differs from the two-pass one only in the order of its
+    floating-point sums)."""
+    box = [] if fused else None
+    segs = change_detect_batch(ctx, d_frames, total_frames, files, rate, cd, timings, text_contract, box)
+    fs = box[0] if box else None
+    if fused and fs is None:                 # no turn at all in the batch
+        return [np.zeros((0, 3)) for _ in files]
+    if fused and any(len(sg) == 0 for sg in segs):
+        # files without segments are not clustering problems: drop them, keep the line order
+        keep = [i for i, sg in enumerate(segs) if len(sg) > 0]
+        out = [np.zeros((0, 3)) for _ in files]
+        if keep:
+            sub = _cluster_and_order(ctx, d_frames, total_frames, [files[i] for i in keep],
+                                     [segs[i] for i in keep], rate, cl, timings, fs)
+            for i, rws in zip(keep, sub):
+                out[i] = rws
+        return out
+    return _cluster_and_order(ctx, d_frames, total_frames, files, segs, rate, cl, timings, fs)
+
+
+def _cluster_and_order(ctx, d_frames, total_frames, files, segs, rate, cl, timings, fs):
+    res = cluster_batch(ctx, d_frames, total_frames, files, segs, rate, cl, timings, fused=fs)
     # recipe order of spk_cluster_hi's output: per file, sorted by (start*rate, end*rate, line)
     cnt = [len(s) for s in segs]
     n = sum(cnt)

@@ -75,16 +75,15 @@ def _emit(seed, stream, n, mu, a):
     return out.astype(np.float32)
 
 
-def make_session(seed, seconds, n_speakers=4, min_turn=3.0, max_turn=15.0,
+def plan_session(seed, seconds, n_speakers=4, min_turn=3.0, max_turn=15.0,
                  sil_seconds=2.0, group=(2, 6), lead_silence=1.0):
-    """Returns (features float32 [T, 39], vad_turns, truth) where
+    """The layout of a session without its samples: (total_frames, pieces, vad_turns,
+    truth) with pieces = [(pos, length, stream, speaker or -1 for silence)] in file order;
     vad_turns = [(start_frame, end_frame)] and truth = [(start, end, speaker)]."""
     total = int(round(seconds * RATE))
-    models = [_speaker_model(seed, k) for k in range(n_speakers)]
     u = _uniform(seed, 1, 4 * (total // (int(min_turn * RATE)) + 16) + 64)
     ui = 0
-    feats = np.empty((total, DIM), dtype=np.float32)
-    vad, truth = [], []
+    pieces, vad, truth = [], [], []
     pos = 0
     stream = 100
     prev = -1
@@ -94,9 +93,8 @@ def make_session(seed, seconds, n_speakers=4, min_turn=3.0, max_turn=15.0,
         n = min(n, total - pos)
         if n <= 0:
             return
-        z = _gauss(seed, stream, n * DIM).reshape(n, DIM)
+        pieces.append((pos, n, stream, -1))
         stream += 1
-        feats[pos:pos + n] = (0.05 * z).astype(np.float32)
         pos += n
 
     silence(int(lead_silence * RATE))
@@ -115,8 +113,7 @@ def make_session(seed, seconds, n_speakers=4, min_turn=3.0, max_turn=15.0,
                     k += 1
             else:
                 k = 0
-            mu, a = models[k]
-            feats[pos:pos + length] = _emit(seed, stream, length, mu, a)
+            pieces.append((pos, length, stream, k))
             stream += 1
             truth.append((pos, pos + length, k))
             pos += length
@@ -127,6 +124,24 @@ def make_session(seed, seconds, n_speakers=4, min_turn=3.0, max_turn=15.0,
             silence(total - pos)
         else:
             silence(int(sil_seconds * RATE))
+    return total, pieces, vad, truth
+
+
+def make_session(seed, seconds, n_speakers=4, min_turn=3.0, max_turn=15.0,
+                 sil_seconds=2.0, group=(2, 6), lead_silence=1.0):
+    """Returns (features float32 [T, 39], vad_turns, truth) where
+    vad_turns = [(start_frame, end_frame)] and truth = [(start, end, speaker)]."""
+    total, pieces, vad, truth = plan_session(seed, seconds, n_speakers, min_turn, max_turn,
+                                             sil_seconds, group, lead_silence)
+    models = [_speaker_model(seed, k) for k in range(n_speakers)]
+    feats = np.empty((total, DIM), dtype=np.float32)
+    for (pos, n, stream, k) in pieces:
+        if k < 0:
+            z = _gauss(seed, stream, n * DIM).reshape(n, DIM)
+            feats[pos:pos + n] = (0.05 * z).astype(np.float32)
+        else:
+            mu, a = models[k]
+            feats[pos:pos + n] = _emit(seed, stream, n, mu, a)
     return feats, vad, truth
 
 

@@ -69,3 +69,34 @@ def test_single_process_gather_is_identity():
     dmod = importlib.import_module('speaker-diarization_amd.distributed')
     assert dmod.gather_texts([(2, 'x\n'), (0, '')]) == {2: 'x\n', 0: ''}
     assert dmod.shard(list('abcde'), 1, 2) == [(1, 'b'), (3, 'd')]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gather_equals_one_rank(tmp_path):
+    """The multi-GPU path of bench.py, driver-style: two fresh child processes started
+    by torch.distributed.run (before anything touches the GPU), one rank each, sharing
+    the box's single GPU (gloo instead of RCCL for that reason).  Rank 0 must have
+    gathered world x files recipes, identical to what one rank produces for the same
+    global file indices."""
+    import subprocess
+    import numpy as np
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    common = ['--steps', '1', '--warmup', '0', '--seconds', '120', '--no-cpu-baseline', '--no-extras']
+    two = os.path.join(str(tmp_path), 'two.npz')
+    one = os.path.join(str(tmp_path), 'one.npz')
+    r2 = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), 'bench.py',
+                         '--gpus', '2', '--backend', 'gloo', '--share-device', '--files', '2',
+                         '--dump-rows', two] + common, cwd=ROOT, env=env, capture_output=True, text=True,
+                        timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    r1 = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--files', '4', '--dump-rows', one] + common,
+                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    import json
+    line = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['verified']['files_gathered'] == 4
+    a, b = np.load(two), np.load(one)
+    assert sorted(a.files) == sorted(b.files) == ['f0', 'f1', 'f2', 'f3']
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]) and len(a[k]) > 3

@@ -298,3 +298,105 @@ def test_dropin_scripts_as_subprocesses(tmp_path):
     assert open(spkc).read() == cd['output_recipe']
     assert open(out).read() == cl['output_recipe']
     assert 'Merging:' in r2.stdout and 'Total detected speakers:' in r2.stdout
+
+
+def _device_batch(n_files, seconds, nspk, seed0):
+    """n_files distinct synthetic sessions generated on the GPU (synth_device.py: the same
+    bytes as synth.make_session), concatenated in HBM.  Returns (frames tensor, files,
+    per-file frame counts, vad lists)."""
+    torch = pytest.importorskip('torch')
+    sd = pkg('synth_device')
+    pipeline = pkg('pipeline')
+    recipe = pkg('recipe')
+    parts, files, vads, off = [], [], [], 0
+    for i in range(n_files):
+        feats, vad, _ = sd.make_session_device(seed0 + i, seconds, nspk, device='cuda')
+        v = [(float(recipe.py2_float_str(a / 125.0)), float(recipe.py2_float_str(b / 125.0))) for a, b in vad]
+        files.append(pipeline.BatchFile(off, feats.shape[0], v))
+        vads.append(vad)
+        parts.append(feats)
+        off += feats.shape[0]
+    return torch.cat(parts), files, vads
+
+
+def test_device_generator_is_bit_identical_to_the_host_one():
+    pytest.importorskip('torch')
+    synth = pkg('synth')
+    sd = pkg('synth_device')
+    for seed, secs, k, kw in ((4242, 150, 3, {}), (31337, 240, 6, dict(min_turn=1.5, max_turn=4.0))):
+        f, v, t = synth.make_session(seed, secs, k, **kw)
+        fd, vd, td = sd.make_session_device(seed, secs, k, device='cuda', **kw)
+        assert synth.fea_sha256(f) == synth.fea_sha256(fd.cpu().numpy())
+        assert v == vd and t == td
+
+
+def test_batch_of_64_one_hour_files(tmp_path):
+    """BASELINE.json config 4 at its size on one GPU: 64 distinct 1 h / 4-speaker files in
+    one launch per stage.  Every file's rows equal those of the same file processed alone
+    (batch == single file), the fused single-read mode gives the same rows, and two of the
+    files are checked against the C oracle through the file-based scripts."""
+    torch = pytest.importorskip('torch')
+    from oracle.c_engine import COracleEngine
+    hipabi = pkg('hipabi')
+    pipeline = pkg('pipeline')
+    synth = pkg('synth')
+    frames, files, vads = _device_batch(64, 3600, 4, 640000)
+    total = int(frames.shape[0])
+    torch.cuda.synchronize()
+    ctx = hipabi.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        tm = {}
+        got = pipeline.diarize_batch(ctx, frames.data_ptr(), total, files, timings=tm)
+        fused = pipeline.diarize_batch(ctx, frames.data_ptr(), total, files, fused=True, timings=tm)
+        assert tm['stats_recomputed'] <= tm['stats_sets'] // 100      # the single read is the rule
+        for i, f in enumerate(files):
+            assert got[i].shape[0] > 200 and np.array_equal(got[i], fused[i]), i
+            alone = pipeline.diarize_batch(ctx, frames.data_ptr(), total, [f])[0]
+            assert np.array_equal(got[i], alone), i
+    finally:
+        ctx.close()
+    for i in (5, 41):
+        f = files[i]
+        feats = frames[f.frame_off:f.frame_off + f.n_frames].cpu().numpy()
+        tmp = os.path.join(str(tmp_path), 'f%d' % i)
+        os.makedirs(os.path.join(tmp, 'fea'))
+        synth.write_fea(os.path.join(tmp, 'fea', 'x.fea'), feats)
+        with open(os.path.join(tmp, 'vad.recipe'), 'w') as fh:
+            fh.write(synth.vad_recipe_text('x.wav', vads[i]))
+        _, final, _, _ = _run_scripts(tmp, COracleEngine(), 'orc')
+        rows = re.findall(r'start-time=(\S+) end-time=(\S+) speaker=speaker_(\d+)', final)
+        want = [(float(a), float(b), int(c)) for a, b, c in rows]
+        assert [(a, b, int(c)) for a, b, c in got[i].tolist()] == want, i
+
+
+def test_ten_hour_file_matches_c_oracle(tmp_path):
+    """BASELINE.json config 5's input on one GPU: a single 10 h / 8-speaker recording
+    (~4 000 segments, ~8 M initial pairs).  Change detection and clustering (launch shape
+    picked by SPKD_AHC_AUTO: the chip-wide form) against the C oracle: recipes and merge
+    sequence identical, merge distances within 1e-9."""
+    torch = pytest.importorskip('torch')
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    sd = pkg('synth_device')
+    feats_d, vad, _ = sd.make_session_device(101010, 36000, 8, device='cuda')
+    feats = feats_d.cpu().numpy()
+    del feats_d
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'day.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(synth.vad_recipe_text('day.wav', vad))
+    e = pkg('engine').HipEngine(0)
+    try:
+        h = _run_scripts(tmp, e, 'hip')
+    finally:
+        e.close()
+    o = _run_scripts(tmp, COracleEngine(), 'orc')
+    assert h[0].count('\n') > 3500
+    assert h[0] == o[0]
+    assert h[1] == o[1]
+    mh, mo = _merge_lines(h[3]), _merge_lines(o[3])
+    assert len(mh) > 3000 and [(a, b) for a, b, _ in mh] == [(a, b) for a, b, _ in mo]
+    worst = max(abs(x[2] - y[2]) / max(1.0, abs(y[2])) for x, y in zip(mh, mo))
+    assert worst < 1e-9, worst
+    print('10 h: %d turns, %d merges, worst merge-distance rel err %.2g' % (h[0].count('\n'), len(mh), worst))

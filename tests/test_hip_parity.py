@@ -7,6 +7,7 @@ labels), scores within 1e-5 relative (fp64); the tests assert tighter bounds."""
 import json
 import math
 import os
+import re
 
 import numpy as np
 import pytest
@@ -67,6 +68,7 @@ def test_pair_terms_against_reference_functions(eng):
         got_glr = cd.glr_from_terms(t)
         if n_small < 40:
             # rank-deficient covariance: the reference's determinant is rounding noise
+            # (pinned separately: test_rank_deficient_sets_are_defined_and_reproducible)
             continue
         assert _rel(got_bic, want_bic) < 1e-9, (p, got_bic, want_bic)
         assert _rel(got_glr, want_glr) < 1e-9, (p, got_glr, want_glr)
@@ -95,6 +97,103 @@ def test_degenerate_inputs_follow_reference(eng):
     # a one-frame set has a NaN covariance: the reference dies with ValueError
     with pytest.raises(ValueError):
         eng.pair_terms([([(0, 1)], [(0, 300)])])
+
+
+def _same_bits(a, b):
+    return (a == b) or (isinstance(a, float) and isinstance(b, float) and math.isnan(a) and math.isnan(b))
+
+
+def test_rank_deficient_sets_are_defined_and_reproducible(eng):
+    """A set with fewer than 40 frames has a rank-deficient covariance: the
+    reference's LU determinant is rounding noise there (NaN for the 30-frame golden pair).
+    include/spkd.h defines what the library returns: no error, the log of the
+    partial-pivoting LU determinant of the fp64 covariance -- noise of its own (a NaN, -inf
+    or a large negative number), bit-reproducible for identical input; KL2 is NaN because
+    the library inverts where the reference takes a pseudo-inverse (documented deviation)."""
+    g = json.load(open(os.path.join(ROOT, 'tests/golden/functions.json')))
+    feats, _, _ = session(g['session'])
+    eng.set_features(feats)
+    short = [p for p in g['pairs'] if min(p['a'][1] - p['a'][0], p['b'][1] - p['b'][0]) < 40]
+    assert short
+    for p in short:
+        job = [([tuple(p['a'])], [tuple(p['b'])])]
+        t1 = eng.pair_terms(job, want_glr=True, want_kl2=True)[0]
+        t2 = eng.pair_terms(job, want_glr=True, want_kl2=True)[0]
+        assert all(_same_bits(x, y) for x, y in zip(t1, t2))
+        n_a = p['a'][1] - p['a'][0]
+        ld_short = t1.logdet1 if n_a < 40 else t1.logdet2
+        assert math.isnan(ld_short) or ld_short < -300.0, ld_short     # 39 pivots, >= 9 of them ~1e-16
+        assert math.isfinite(t1.logdet2 if n_a < 40 else t1.logdet1)   # the full-rank partner is untouched
+        # the reference's own values for this pair are NaN (BIC, GLR) and a finite pinv-based KL2
+        assert math.isnan(float.fromhex(p['cl_bic_l1.3'])) and math.isfinite(float.fromhex(p['kl2']))
+        assert math.isnan(t1.kl2)
+    # in the clustering kernels the same records go through the four-per-wave elimination
+    # and its pivoting fallback: same definition, same reproducibility
+    segs = [tuple(short[0]['a']), tuple(short[0]['b']), (1241, 1900), (125, 1241)]
+    r1 = eng.cluster_hi(segs, 1, 'BIC', 1.3, 0.0, 0)
+    r2 = eng.cluster_hi(segs, 1, 'BIC', 1.3, 0.0, 0)
+    assert len(r1.merges) == len(r2.merges)
+    assert all(_same_bits(float(x[2]), float(y[2])) and x[:2] == y[:2] for x, y in zip(r1.merges, r2.merges))
+
+
+def test_sliding_window_bic_kernel_against_reference_function(eng):
+    """`-m sw -d BIC` crashes in the reference (the host raises the same
+    error), but spkd_sw's BIC branch is part of the ABI: checked here against the
+    reference's own bic() on the windows dist_sw would cut (functions_sw.json)."""
+    g = json.load(open(os.path.join(ROOT, 'tests/golden/functions_sw.json')))
+    feats, _, _ = session(g['session'])
+    eng.set_features(feats)
+    worst = 0.0
+    for w in g['windows']:
+        want = np.array([float.fromhex(v) for v in w['bic']])
+        got = eng.sw([tuple(w['turn'])], 'BIC', w['lambda'], w['winsize'], w['winstep'])[0]
+        assert len(got) == len(want) and len(want) > 3
+        err = float(np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))))
+        assert err < 1e-9, (w['turn'], err)
+        worst = max(worst, err)
+    print('worst two-window BIC relative error vs the reference function: %.3g' % worst)
+
+
+def test_kl2_deviations_are_the_documented_ones(eng):
+    """KL2 where a covariance is not positive definite: the reference's
+    SVD pinv gives a finite pseudo-inverse, the library's inverse gives NaN.  With two
+    digital-silence segments in an AHC problem the NaN distances make numpy-style min()
+    NaN: no merge at all unless -ms forces merging, and then every merge distance is NaN."""
+    synth = pkg('synth')
+    feats, _, truth = synth.make_session(4242, 600, 4)
+    segs = [(a, b) for a, b, _ in truth][:20]
+    f = feats.copy()
+    for z in (3, 11):
+        f[segs[z][0]:segs[z][1]] = 0.0
+    eng.set_features(f)
+    t = eng.pair_terms([([segs[3]], [segs[0]])], want_kl2=True)[0]
+    assert math.isnan(t.kl2)
+    free = eng.cluster_hi(segs, 1, 'KL2', 1.3, 12.0, 0)
+    assert free.merges == []
+    forced = eng.cluster_hi(segs, 1, 'KL2', 1.3, 12.0, 5)
+    assert len(forced.merges) == len(segs) - 5
+    assert all(math.isnan(d) for _, _, d in forced.merges)
+
+
+def test_integration_md_ctypes_stub_runs():
+    """The ctypes stub INTEGRATION.md shows a maintainer of the reference (its `bic`
+    with the signature of spk-clustering.py:81) is executed as written -- only the library
+    path is made absolute -- and reproduces the reference's own values."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r"```python\n(# spkd_stub\.py.*?)```", text, flags=re.S)
+    assert m, 'stub code block not found in INTEGRATION.md'
+    code = m.group(1)
+    assert "C.CDLL('libspkd_hip.so')" in code
+    code = code.replace("C.CDLL('libspkd_hip.so')", 'C.CDLL(%r)' % pkg('hipabi').LIB_PATH)
+    ns = {}
+    exec(compile(code, 'spkd_stub.py', 'exec'), ns)
+    g = json.load(open(os.path.join(ROOT, 'tests/golden/functions.json')))
+    feats, _, _ = session(g['session'])
+    for p in g['pairs'][:4]:
+        x, y = feats[p['a'][0]:p['a'][1]], feats[p['b'][0]:p['b'][1]]
+        got = ns['bic'](x, y, lambdac=g['lambda'])
+        want = float.fromhex(p['cl_bic_l1.3'])
+        assert _rel(got, want) < 1e-9, (p['a'], p['b'], got, want)
 
 
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
