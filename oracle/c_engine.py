@@ -63,6 +63,14 @@ class COracleEngine(object):
         """threads: OpenMP threads of the clustering loops (0 = all cores, 1 = the scalar
         port); results do not depend on it."""
         self.lib = _load()
+        if int(threads) <= 0:
+            # all cores this process may use, at most 16 (the GPU boxes give a job a 16-CPU
+            # share of a much larger machine: one thread per visible core would thrash)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            threads = max(1, min(avail, 16))
         self.threads = self.lib.orc_set_threads(int(threads))
         self.f = None
 

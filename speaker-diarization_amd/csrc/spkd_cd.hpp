@@ -103,6 +103,15 @@ __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long 
     }
 }
 
+// row-per-lane rows of a quad-layout record (the sliding window's snapshots)
+__device__ __forceinline__ void single_rows_from_qr(const double* __restrict__ qr, double (&q)[DA]) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;           // lanes >= 39 mirror row 38 (ignored)
+    const int base = (i / QL) * DA * 16 + (i % QL);
+#pragma unroll
+    for (int j = 0; j < DA; ++j) q[j] = qr[base + j * 16];
+}
+
 // Row-per-lane (single matrix) prefix rows from the snapshots (sliding window).
 __device__ __forceinline__ void single_prefix_rows(double (&q)[DA], const double* __restrict__ snap,
                                                    const float* __restrict__ fr, long long t) {
@@ -210,9 +219,6 @@ __device__ __forceinline__ int tri_slot(int r, int j) {
     return TREC_COUNT_AT;
 }
 
-// the same entry in a packed record (= pk(j, r): upper triangle row-major by symmetry)
-__host__ __device__ constexpr int pk_low(int r, int j) { return pk_off(j) + (r - j); }
-
 // row-per-lane (single matrix) rows of a tri record / a packed record, by symmetry
 __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (&q)[DA]) {
     int i = lane_id();
@@ -220,14 +226,6 @@ __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (
 #pragma unroll
     for (int j = 0; j < D; ++j) q[j] = rec[j <= i ? tri_slot(i, j) : tri_slot(j, i)];
     q[D] = rec[tri_slot(D, i)];
-}
-
-__device__ __forceinline__ void single_rows_from_packed(const double* __restrict__ rec, double (&q)[DA]) {
-    int i = lane_id();
-    i = i >= D ? D - 1 : i;
-#pragma unroll
-    for (int j = 0; j < D; ++j) q[j] = rec[j <= i ? pk_low(i, j) : pk_low(j, i)];
-    q[D] = rec[pk_low(D, i)];
 }
 
 // ---------------------------------------------------------------------------
@@ -543,9 +541,17 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
 // two: the launch has GLR items (wave-uniform; the second rank-one term is skipped
 // otherwise).  DPP rows that name the same record (the left and the right item of a
 // new candidate sit side by side) fetch it once: their loads coalesce.
+// pf_rec / pf_lds: the record this DPP row's item of the wave's NEXT pass will read, and a
+// 256-byte LDS landing pad of the wave (nullptr: nothing to prefetch).  Four LDS-DMA loads
+// of one dword per lane, issued behind this pass's own loads, touch every 128-byte piece
+// of that record, so that it sits in L2 when the next pass asks for it: within a wave a
+// pass is load -> wait -> eliminate, and the HBM latency of the 81 loads was exposed
+// whenever the SIMD's other wave was not computing.  Nothing ever reads the landing pad.
+#define SPKD_LDS __attribute__((address_space(3)))
 __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const double* ldsEnd,
                                                     const double* __restrict__ rec_b,
-                                                    double n1, double n2, const QuadLane& L, int* err) {
+                                                    double n1, double n2, const QuadLane& L, int* err,
+                                                    const double* pf_rec = nullptr, int* pf_lds = nullptr) {
     QuadRows q;
     double svb[QS];
     int ta = L.t;
@@ -554,20 +560,28 @@ __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const do
     double al, ga, k1a, k1c, k2a, k2c, w1, w2;
     // v1 = k1a * s_b + k1c * s_c ;  c1 = w1 * v1  (same for v2, c2)
     {
-        const bool glr = pass == PASS_GLR;
-        const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);     // GLR lanes only
+        // (an IEEE fp64 division is ~25 instructions: the GLR weights are only formed in
+        // launches that have GLR items, the covariance scale uses the Newton reciprocal)
+        const bool glr = two && pass == PASS_GLR;
+        double al1 = 0.0, al2 = 0.0, b1 = 0.0, b2 = 0.0;
+        if (two) {                          // wave-uniform
+            al1 = (n1 / n) / (n1 - 1.0);
+            al2 = (n2 / n) / (n2 - 1.0);
+            b1 = al1 / n1;
+            b2 = al2 / n2;
+        }
         const double np = pass == PASS_RIGHT ? n2 : (pass == PASS_LEFT ? n1 : n);
-        const double f = 1.0 / (np - 1.0);
+        const double f = fast_recip(np - 1.0);
         const double sa = pass == PASS_RIGHT ? -1.0 : (pass == PASS_LEFT ? 1.0 : 0.0);
         const double sg = pass == PASS_LEFT ? 0.0 : 1.0;
         al = glr ? al1 - al2 : sa * f;      // covariance scale folded into the combine
         ga = glr ? al2 : sg * f;
         k1a = glr ? 1.0 : sa;
         k1c = glr ? 0.0 : sg;
-        w1 = glr ? -(al1 / n1) : -(f / np);
+        w1 = glr ? -b1 : -(f * fast_recip(np));
         k2a = glr ? -1.0 : 0.0;
         k2c = glr ? 1.0 : 0.0;
-        w2 = glr ? -(al2 / n2) : 0.0;
+        w2 = glr ? -b2 : 0.0;
     }
     {
         // 81 loads in flight, one latency.  One base pointer per 4 KB (the immediate
@@ -591,6 +605,15 @@ __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const do
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (pf_lds) {                                        // wave-uniform
+        const char* pb = (const char*)pf_rec;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int piece = ta + 16 * u;              // 52 pieces of 128 B; the rest re-touch the last dword
+            const int off = piece < 52 ? piece * 128 : REC * 8 - 4;
+            __builtin_amdgcn_global_load_lds((const SPKD_GLOBAL void*)(pb + off), (SPKD_LDS void*)pf_lds, 4, 0, 0);
+        }
+    }
     double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -676,6 +699,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     __shared__ GwState S;
+    __shared__ int s_pf[GW_WAVES * 64];              // landing pads of the record prefetch (never read)
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
     const TurnDesc T = turns[blockIdx.x];
@@ -843,12 +867,8 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             const long long base2 = left0 + padA;
             const long long M = glr_kind ? 2 * count + nnew
                                          : base2 + 2 * nnew + ((pooled && !padA) ? 1 : 0);
-            for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
-                long long it = 4 * q4 + L.m;
-                bool valid = it < M;
-                it = valid ? it : M - 1;
-                int pass;
-                long long k;
+            // item index -> (pass, candidate); false for the idle pad item
+            auto decode = [&](long long it, int& pass, long long& k) -> bool {
                 if (glr_kind) {
                     if (it < 2 * count) { k = it >> 1; pass = (it & 1) ? PASS_GLR : PASS_RIGHT; }
                     else { k = left0 + (it - 2 * count); pass = PASS_LEFT; }
@@ -856,7 +876,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                     pass = PASS_RIGHT; k = it;
                 } else if (padA && it == left0) {
                     if (pooled) { pass = PASS_POOLED; k = 0; }
-                    else { pass = PASS_RIGHT; k = it - 1; valid = false; }
+                    else { pass = PASS_RIGHT; k = it - 1; return false; }
                 } else if (it < base2 + 2 * nnew) {
                     const long long j = it - base2;
                     k = left0 + (j >> 1);
@@ -864,13 +884,33 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 } else {
                     pass = PASS_POOLED; k = 0;
                 }
+                return true;
+            };
+            int* pf_pad = s_pf + 64 * __builtin_amdgcn_readfirstlane(wave);
+            for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
+                long long it = 4 * q4 + L.m;
+                bool valid = it < M;
+                it = valid ? it : M - 1;
+                int pass;
+                long long k;
+                if (!decode(it, pass, k)) valid = false;
+                // the record this row's item of the wave's next pass will want
+                const bool more = 4 * (q4 + GW_WAVES) < M;
+                long long kn = k;
+                if (more) {
+                    long long itn = 4 * (q4 + GW_WAVES) + L.m;
+                    itn = itn < M ? itn : M - 1;
+                    int pn;
+                    (void)decode(itn, pn, kn);
+                }
                 const long long slot = base + k;
                 // (no candidates at all: the only item is the pooled window; record 0 is still a
                 // finite record of this or an earlier epoch, or zero-initialised scratch)
                 const double ik = count > 0 ? c_i[slot] : 0.0;
                 const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
                 const double n1 = (double)(b - a), n2 = (double)(c - b);
-                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err);
+                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err,
+                                                   cache + (base + kn) * REC, more ? pf_pad : nullptr);
                 if (valid && L.t == 0) {
                     if (pass == PASS_POOLED) s_ldS = v;
                     else if (pass == PASS_RIGHT) c_x[slot] = v;

@@ -24,6 +24,10 @@ constexpr int REC_PER_LANE = 13;   // ceil(820 / 64)
 __host__ __device__ constexpr int pk_off(int r) { return r * DA - (r * (r - 1)) / 2; }
 __host__ __device__ constexpr int pk(int r, int c) { return pk_off(r) + (c - r); }   // r <= c
 
+// entry (row r, column j <= r) of the lower triangle in a packed record: by symmetry
+// pk(j, r), so column j holds its rows j .. 39 contiguously from pk_off(j)
+__host__ __device__ constexpr int pk_low(int r, int j) { return pk_off(j) + (r - j); }
+
 __device__ __forceinline__ void decode_entry(int e, int& r, int& c) {
     int rr = 0;
 #pragma unroll 1

@@ -352,13 +352,15 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     B.smin = B.smax + n_prob;
     HIPCHK(c, hipMemsetAsync(B.smax, 0x00, (size_t)n_prob * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(B.smin, 0xff, (size_t)n_prob * sizeof(unsigned long long), c->stream));
-    if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * QREC * sizeof(double), &p)) != SPKD_OK) return st;
+    // a private working copy of the records (clusters are merged in place)
+    if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * REC * sizeof(double), &p)) != SPKD_OK) return st;
     B.ex = (double*)p;
+    if (n_total > 0)
+        HIPCHK(c, hipMemcpyAsync(B.ex, d_stats, (size_t)n_total * REC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     if (n_total > 0) {
         // KL2: one wave per record; BIC / GLR: four records per wave
         const int64_t per_block = kind == SPKD_KL2 ? PT_WAVES : 4 * PT_WAVES;
         const unsigned blocks = (unsigned)((n_total + per_block - 1) / per_block);
-        hipLaunchKernelGGL(k_to_quadrec, dim3((unsigned)n_total), dim3(256), 0, c->stream, d_stats, n_total, B.ex);
         TIMED(c, SPKD_T_CLUSTER_PREP,
               hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
                                  (const double*)B.ex, n_total, kind, B.ld, B.aux, c->d_err));

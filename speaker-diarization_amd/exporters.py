@@ -4,8 +4,12 @@
   * DER      -- frame-level (1 ms) speaker-error rate of a proposed recipe against a
                 baseline, greedy one-to-one-by-count label matching  clus-performance.py:9-108
 
-aku2elan.py (ELAN XML through lxml, with a wall-clock DATE attribute) is not rebuilt:
-lxml is not available in this environment and its output is not reproducible anyway.
+  * aku2elan -- recipe -> ELAN .eaf (EAF 2.7 XML) ................... aku2elan.py:10-99
+                PARITY UNPINNED: the reference writes through lxml, which is not installed
+                here, so no reference output could be generated; the document structure,
+                attribute values and the two-space pretty print follow the source, the
+                attribute order is the one the source spells (Python 2 / lxml order is a
+                dict-hash artefact), and DATE is the wall clock as in the reference.
 """
 import argparse
 import re
@@ -69,6 +73,96 @@ def main_aku2ann(argv=None, stdout=None):
     else:
         say('Writing output to: stdout')
         write_ann(recipe, out)
+    return None
+
+
+# --------------------------------------------------------------------------- aku2elan
+def date_iso(now=None, utcnow=None):
+    """Local time in ISO format with the UTC offset, as ELAN expects it (aku2elan.py:10-17)."""
+    from datetime import datetime
+    dtnow = now or datetime.now()
+    dtutcnow = utcnow or datetime.utcnow()
+    delta = dtnow - dtutcnow
+    hh, mm = divmod((delta.days * 24 * 60 * 60 + delta.seconds + 30) // 60, 60)
+    return '%s%+02d:%02d' % (dtnow.isoformat(), hh, mm)
+
+
+def _xml_attr(v):
+    return v.replace('&', '&amp;').replace('<', '&lt;').replace('"', '&quot;')
+
+
+def _xml_text(v):
+    return v.replace('&', '&amp;').replace('<', '&lt;').replace('>', '&gt;')
+
+
+def write_elan(recipe, outf, date=None):
+    """ELAN document of a recipe: two time slots per line (milliseconds, truncated) and one
+    alignable annotation per line on a single `Speakers` tier (aku2elan.py:45-99)."""
+    from mimetypes import guess_type
+
+    def tag(indent, name, attrs, text=None, close=True):
+        a = ''.join(' %s="%s"' % (k, _xml_attr(v)) for k, v in attrs)
+        pad = '  ' * indent
+        if text is not None:
+            outf.write('%s<%s%s>%s</%s>\n' % (pad, name, a, _xml_text(text), name))
+        elif close:
+            outf.write('%s<%s%s/>\n' % (pad, name, a))
+        else:
+            outf.write('%s<%s%s>\n' % (pad, name, a))
+
+    outf.write('<ANNOTATION_DOCUMENT xmlns:xsi="http://www.w3.org/2001/XMLSchema-instance"'
+               ' xsi:noNamespaceSchemaLocation="http://www.mpi.nl/tools/elan/EAFv2.7.xsd"'
+               ' AUTHOR="" DATE="%s" FORMAT="2.7" VERSION="2.7">\n' % _xml_attr(date or date_iso()))
+    tag(1, 'HEADER', [('MEDIA_FILE', ''), ('TIME_UNITS', 'milliseconds')], close=False)
+    tag(2, 'MEDIA_DESCRIPTOR', [('MEDIA_URL', 'file://' + recipe[0][0]),
+                                ('MIME_TYPE', guess_type(recipe[0][0])[0] or ''),
+                                ('RELATIVE_MEDIA_URL', '')])
+    tag(2, 'PROPERTY', [('NAME', 'lastUsedAnnotationId')], text=str(len(recipe)))
+    outf.write('  </HEADER>\n')
+    tag(1, 'TIME_ORDER', [], close=False)
+    ts = 1
+    for line in recipe:
+        for t in (line[2], line[3]):
+            tag(2, 'TIME_SLOT', [('TIME_SLOT_ID', 'ts%d' % ts), ('TIME_VALUE', str(int(t * 1000)))])
+            ts += 1
+    outf.write('  </TIME_ORDER>\n')
+    tag(1, 'TIER', [('DEFAULT_LOCALE', 'en'), ('LINGUISTIC_TYPE_REF', 'default-lt'), ('TIER_ID', 'Speakers')],
+        close=False)
+    for n, line in enumerate(recipe, 1):
+        tag(2, 'ANNOTATION', [], close=False)
+        ref = [('ANNOTATION_ID', 'a%d' % n), ('TIME_SLOT_REF1', 'ts%d' % (2 * n - 1)),
+               ('TIME_SLOT_REF2', 'ts%d' % (2 * n))]
+        if line[4]:
+            tag(3, 'ALIGNABLE_ANNOTATION', ref, close=False)
+            tag(4, 'ANNOTATION_VALUE', [], text=line[4])
+            outf.write('      </ALIGNABLE_ANNOTATION>\n')
+        else:
+            tag(3, 'ALIGNABLE_ANNOTATION', ref)
+        outf.write('    </ANNOTATION>\n')
+    outf.write('  </TIER>\n')
+    tag(1, 'LINGUISTIC_TYPE', [('GRAPHIC_REFERENCES', 'false'), ('LINGUISTIC_TYPE_ID', 'default-lt'),
+                               ('TIME_ALIGNABLE', 'true')])
+    tag(1, 'LOCALE', [('COUNTRY_CODE', 'US'), ('LANGUAGE_CODE', 'en')])
+    outf.write('</ANNOTATION_DOCUMENT>\n')
+
+
+def main_aku2elan(argv=None, stdout=None, date=None):
+    out = stdout or sys.stdout
+    say = _say_to(out)
+    p = argparse.ArgumentParser(description='Converts an AKU recipe to Elan format.')
+    p.add_argument('recfile', type=str, help='Specifies the input recipe file')
+    p.add_argument('-o', dest='outfile', type=str, default=None, help='Specifies an output file, default stdout.')
+    args = p.parse_args(argv)
+    say('Reading recipe from:', args.recfile)
+    with open(args.recfile, 'r') as f:
+        recipe = parse_recipe_ann(f, say)           # same five fields, same regexes (aku2elan.py:20-42)
+    if args.outfile is not None:
+        say('Writing output to:', args.outfile)
+        with open(args.outfile, 'w') as outf:
+            write_elan(recipe, outf, date)
+    else:
+        say('Writing output to: stdout')
+        write_elan(recipe, out, date)
     return None
 
 
