@@ -103,15 +103,6 @@ __device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long 
     }
 }
 
-// row-per-lane rows of a quad-layout record (the sliding window's snapshots)
-__device__ __forceinline__ void single_rows_from_qr(const double* __restrict__ qr, double (&q)[DA]) {
-    int i = lane_id();
-    i = i >= D ? D - 1 : i;           // lanes >= 39 mirror row 38 (ignored)
-    const int base = (i / QL) * DA * 16 + (i % QL);
-#pragma unroll
-    for (int j = 0; j < DA; ++j) q[j] = qr[base + j * 16];
-}
-
 // Row-per-lane (single matrix) prefix rows from the snapshots (sliding window).
 __device__ __forceinline__ void single_prefix_rows(double (&q)[DA], const double* __restrict__ snap,
                                                    const float* __restrict__ fr, long long t) {
@@ -206,19 +197,6 @@ enum { PASS_RIGHT = 0, PASS_LEFT = 1, PASS_GLR = 2, PASS_POOLED = 3 };
 // inside the record, and the value lands in a register nobody reads (spkd_tri.hpp).
 // 6 560 B per candidate instead of the 10 368 B of a padded tri record.
 // ---------------------------------------------------------------------------
-constexpr int TLINES = 3 * QL + 3 * QL + 3;                  // 13 + 26 + 39 + 3 = 81
-constexpr int TREC = TLINES * 16;                            // 1 296 doubles = 10 368 B
-constexpr int TREC_SUMS = 6 * QL;                            // first sums line (78)
-constexpr int TREC_COUNT_AT = TREC_SUMS * 16 + 15;
-__host__ __device__ constexpr int tri_off(int s) { return s == 0 ? 0 : (s == 1 ? QL : 3 * QL); }
-
-// entry (row r, column j <= r) of the 40x40 augmented matrix -> index in a tri record
-__device__ __forceinline__ int tri_slot(int r, int j) {
-    if (r < D) { const int s = r / QL; return (tri_off(s) + j) * 16 + (r - QL * s); }
-    if (j < D) { const int s = j / QL; return (TREC_SUMS + s) * 16 + (j - QL * s); }
-    return TREC_COUNT_AT;
-}
-
 // row-per-lane (single matrix) rows of a tri record / a packed record, by symmetry
 __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (&q)[DA]) {
     int i = lane_id();
@@ -541,17 +519,9 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
 // two: the launch has GLR items (wave-uniform; the second rank-one term is skipped
 // otherwise).  DPP rows that name the same record (the left and the right item of a
 // new candidate sit side by side) fetch it once: their loads coalesce.
-// pf_rec / pf_lds: the record this DPP row's item of the wave's NEXT pass will read, and a
-// 256-byte LDS landing pad of the wave (nullptr: nothing to prefetch).  Four LDS-DMA loads
-// of one dword per lane, issued behind this pass's own loads, touch every 128-byte piece
-// of that record, so that it sits in L2 when the next pass asks for it: within a wave a
-// pass is load -> wait -> eliminate, and the HBM latency of the 81 loads was exposed
-// whenever the SIMD's other wave was not computing.  Nothing ever reads the landing pad.
-#define SPKD_LDS __attribute__((address_space(3)))
 __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const double* ldsEnd,
                                                     const double* __restrict__ rec_b,
-                                                    double n1, double n2, const QuadLane& L, int* err,
-                                                    const double* pf_rec = nullptr, int* pf_lds = nullptr) {
+                                                    double n1, double n2, const QuadLane& L, int* err) {
     QuadRows q;
     double svb[QS];
     int ta = L.t;
@@ -605,15 +575,6 @@ __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const do
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (pf_lds) {                                        // wave-uniform
-        const char* pb = (const char*)pf_rec;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int piece = ta + 16 * u;              // 52 pieces of 128 B; the rest re-touch the last dword
-            const int off = piece < 52 ? piece * 128 : REC * 8 - 4;
-            __builtin_amdgcn_global_load_lds((const SPKD_GLOBAL void*)(pb + off), (SPKD_LDS void*)pf_lds, 4, 0, 0);
-        }
-    }
     double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -699,7 +660,6 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     __shared__ GwState S;
-    __shared__ int s_pf[GW_WAVES * 64];              // landing pads of the record prefetch (never read)
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
     const TurnDesc T = turns[blockIdx.x];
@@ -886,7 +846,6 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 }
                 return true;
             };
-            int* pf_pad = s_pf + 64 * __builtin_amdgcn_readfirstlane(wave);
             for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
                 long long it = 4 * q4 + L.m;
                 bool valid = it < M;
@@ -894,23 +853,13 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 int pass;
                 long long k;
                 if (!decode(it, pass, k)) valid = false;
-                // the record this row's item of the wave's next pass will want
-                const bool more = 4 * (q4 + GW_WAVES) < M;
-                long long kn = k;
-                if (more) {
-                    long long itn = 4 * (q4 + GW_WAVES) + L.m;
-                    itn = itn < M ? itn : M - 1;
-                    int pn;
-                    (void)decode(itn, pn, kn);
-                }
                 const long long slot = base + k;
                 // (no candidates at all: the only item is the pooled window; record 0 is still a
                 // finite record of this or an earlier epoch, or zero-initialised scratch)
                 const double ik = count > 0 ? c_i[slot] : 0.0;
                 const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
                 const double n1 = (double)(b - a), n2 = (double)(c - b);
-                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err,
-                                                   cache + (base + kn) * REC, more ? pf_pad : nullptr);
+                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err);
                 if (valid && L.t == 0) {
                     if (pass == PASS_POOLED) s_ldS = v;
                     else if (pass == PASS_RIGHT) c_x[slot] = v;

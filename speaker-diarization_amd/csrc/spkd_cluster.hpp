@@ -161,17 +161,30 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_pair_terms(
 }
 
 // ---------------------------------------------------------------------------
-// The clustering kernels read the ABI's packed records (6 560 B) directly: by symmetry a
-// packed record is the lower triangle column by column, so the four-matrices-per-wave
-// load of (slot s, column j) is 13 consecutive doubles at pk_off(j) + 13 s - j + t (lanes
-// of a diagonal block above the diagonal read the previous column's tail: inside the
-// record, into registers nobody reads).  Round 1 expanded every record to a 15 360-byte
-// "quad record" first; the merge loop is bound by the stream of partner records from HBM
-// (each problem's records exceed its share of L2), so the bytes per pair matter.
-// Only the row's own record, which all pairs of a pass share, is expanded -- into LDS,
-// in the quad layout of spkd_quad.hpp (conflict-free for the formation's reads).
+// Packed -> quad records (see spkd_quad.hpp).  The packed form (6 560 B) stays the
+// ABI format; the clustering kernels keep their working set as quad records.
+__global__ __launch_bounds__(256) void k_to_quadrec(const double* __restrict__ packed, int64_t n_rec,
+                                                    double* __restrict__ qr) {
+    const int64_t c = blockIdx.x;
+    if (c >= n_rec) return;
+    const double* g = packed + c * REC;
+    double* o = qr + c * QREC;
+    for (int e = threadIdx.x; e < QREC; e += 256) {
+        const int t = e & 15, sj = e >> 4;
+        const int s = sj / DA, j = sj - s * DA;
+        double v = 0.0;
+        if (t < QL) {
+            const int i = QL * s + t;
+            const int r = i < j ? i : j, cc = i < j ? j : i;
+            v = g[pk(r, cc)];
+        } else if (e == QREC_COUNT_AT) {
+            v = g[REC - 1];
+        }
+        o[e] = v;
+    }
+}
 
-// row-per-lane (single matrix) rows of a packed record, by symmetry
+// row-per-lane (single matrix) rows of a packed record, by symmetry (k_gw's cache records)
 __device__ __forceinline__ void single_rows_from_packed(const double* __restrict__ rec, double (&q)[DA]) {
     int i = lane_id();
     i = i >= D ? D - 1 : i;           // lanes >= 39 mirror row 38 (ignored)
@@ -180,46 +193,25 @@ __device__ __forceinline__ void single_rows_from_packed(const double* __restrict
     q[D] = rec[pk_low(D, i)];
 }
 
-__device__ __forceinline__ double rec_count(const double* __restrict__ rec) { return rec[REC - 1]; }
-
-// value of element idx of the quad-layout LDS image of a packed record
-// (idx = (s * 40 + j) * 16 + t -> M(13 s + t, j); column 39 = sums; the count in the
-// padding lane QREC_COUNT_AT; the part of a diagonal block above the diagonal is filled
-// by symmetry)
-__device__ __forceinline__ int quad_image_source(int idx) {
-    const int t = idx & 15, sj = idx >> 4;
-    const int s = sj / DA, j = sj - s * DA;
-    if (t >= QL) return idx == QREC_COUNT_AT ? REC - 1 : -1;
-    const int r = QL * s + t;
-    return r >= j ? pk_low(r, j) : pk_low(j, r);
-}
-
-__device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
-    for (int e = tid; e < QREC; e += nthreads) {
-        const int src = quad_image_source(e);
-        lds[e] = src >= 0 ? g[src] : 0.0;
-    }
-}
-
-// lds = quad image of (A + B)
-__device__ __forceinline__ void stage_record_sum(double* lds, const double* __restrict__ ga,
-                                                 const double* __restrict__ gb, int tid, int nthreads) {
-    for (int e = tid; e < QREC; e += nthreads) {
-        const int src = quad_image_source(e);
-        lds[e] = src >= 0 ? ga[src] + gb[src] : 0.0;
-    }
+// row-per-lane (single matrix) forms used by the pivoting fallback and by KL2
+__device__ __forceinline__ void single_rows_from_qr(const double* __restrict__ qr, double (&q)[DA]) {
+    int i = lane_id();
+    i = i >= D ? D - 1 : i;           // lanes >= 39 mirror row 38 (ignored)
+    const int base = (i / QL) * DA * 16 + (i % QL);
+#pragma unroll
+    for (int j = 0; j < DA; ++j) q[j] = qr[base + j * 16];
 }
 
 // matrix whose log det a pair distance needs, row-per-lane layout
 __device__ __forceinline__ void single_pair_matrix(int kind, const double* __restrict__ qrA,
                                                    const double* __restrict__ qrC, bool self,
                                                    double (&q)[DA]) {
-    const double nA = rec_count(qrA);
-    single_rows_from_packed(qrA, q);
+    const double nA = qr_count(qrA);
+    single_rows_from_qr(qrA, q);
     if (self) { cov_rows(q, nA); return; }
-    const double nC = rec_count(qrC), n = nA + nC;
+    const double nC = qr_count(qrC), n = nA + nC;
     double q2[DA];
-    single_rows_from_packed(qrC, q2);
+    single_rows_from_qr(qrC, q2);
     if (kind == SPKD_BIC) {
 #pragma unroll
         for (int j = 0; j < DA; ++j) q[j] += q2[j];
@@ -254,7 +246,7 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
                                                    const double* __restrict__ qrC, bool self,
                                                    const QuadLane& L, const double* const* qrC_by_m,
                                                    const bool* self_by_m, int* err) {
-    const double nC = self ? 0.0 : rec_count(qrC);
+    const double nC = self ? 0.0 : qr_count(qrC);
     const double n = nA + nC;
     const bool glr = TWO && (kind == SPKD_GLR && !self);
     // (an IEEE fp64 division is ~25 instructions; the covariance scale uses the Newton
@@ -270,29 +262,16 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
             k2 = -(wc / nC);
         }
     }
+    const double* Ct = qrC + L.t;
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keeps A's LDS reads inside the caller's loop
     QuadRows q;
     double sc[QS];
-    {
-        // 81 loads in flight, one latency; one base pointer per 4 KB of the record (the
-        // immediate offset of a global load spans 4 KB)
-        const int t12 = ta < QL ? ta : QL - 1;          // idle lanes 13..15 ride with lane 12
-        const double* rt[2];
-        long long o1 = 512;                 // opaque, so that the bases stay separate registers
-        asm volatile("" : "+v"(o1));
-        rt[0] = qrC + t12;
-        rt[1] = rt[0] + o1;
 #pragma unroll
-        for (int s = 0; s < QS; ++s) {
+    for (int s = 0; s < QS; ++s) {        // 81 loads in flight, one latency
 #pragma unroll
-            for (int j = 0; j < tri_cols(s); ++j) {
-                const int e = pk_off(j) + QL * s - j;   // + t12 (in the base)
-                q.r[s][j] = rt[e / 512][e % 512];
-            }
-            const int c = QL * s + t12;                 // this lane's row of slot s
-            sc[s] = qrC[pk_off(c) + D - c];             // (39, c): the sums entry of column c
-        }
+        for (int j = 0; j < tri_cols(s); ++j) q.r[s][j] = Ct[(s * DA + j) * 16];
+        sc[s] = Ct[(s * DA + D) * 16];
     }
     __builtin_amdgcn_sched_barrier(0);
     double v1[QS], v2[QS], c1[QS], c2[QS];
@@ -317,6 +296,10 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
     return tri_logdet(q, L.m, err, form_single);
 }
 
+__device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
+    for (int e = tid; e < QREC; e += nthreads) lds[e] = g[e];
+}
+
 // ---------------------------------------------------------------------------
 // per-record cached terms: log det S (BIC / GLR) or the KL2 vectors
 __global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
@@ -326,10 +309,10 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
     const int64_t w = (int64_t)blockIdx.x * PT_WAVES + wave;
     if (kind == SPKD_KL2) {
         if (w >= n_rec) return;
-        const double* R = qr + w * REC;
+        const double* R = qr + w * QREC;
         double a[DA];
-        single_rows_from_packed(R, a);
-        const double n = rec_count(R);
+        single_rows_from_qr(R, a);
+        const double n = qr_count(R);
         const double mean_i = a[D] / n;
         cov_rows(a, n);
         kl2_aux_from_cov(a, mean_i, aux + w * AUX);
@@ -344,35 +327,19 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
     for (int mi = 0; mi < 4; ++mi) {
         int64_t c = w * 4 + mi;
         c = c < n_rec ? c : n_rec - 1;
-        recs[mi] = qr + c * REC;
+        recs[mi] = qr + c * QREC;
         selfs[mi] = true;
     }
     int64_t c = w * 4 + L.m;
     const bool valid = c < n_rec;
     c = valid ? c : n_rec - 1;
-    const double* R = qr + c * REC;
-    // every DPP row takes its own record
+    const double* R = qr + c * QREC;
+    // every DPP row takes its own record as "A": formed in the single-matrix path
+    // of quad_pair_logdet with self = true through a per-lane pointer
     QuadRows q;
     double sv[QS];
-    const double nR = rec_count(R), fR = fast_recip(nR - 1.0);
-    {
-        const int t12 = L.t < QL ? L.t : QL - 1;
-        const double* rt[2];
-        long long o1 = 512;
-        asm volatile("" : "+v"(o1));
-        rt[0] = R + t12;
-        rt[1] = rt[0] + o1;
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-#pragma unroll
-            for (int j = 0; j < tri_cols(s); ++j) {
-                const int e = pk_off(j) + QL * s - j;
-                q.r[s][j] = fR * rt[e / 512][e % 512];
-            }
-            const int cc = QL * s + t12;
-            sv[s] = R[pk_off(cc) + D - cc];
-        }
-    }
+    const double nR = qr_count(R), fR = fast_recip(nR - 1.0);
+    quad_load_scaled(R, L.t, fR, q, sv);
     double c1[QS];
     const double gR = -(fR * fast_recip(nR));
 #pragma unroll
@@ -403,7 +370,10 @@ __device__ __forceinline__ int find_problem(const int64_t* __restrict__ seg_off,
     return (int)lo;
 }
 
-constexpr int MX_WAVES = 4;
+#ifndef SPKD_MX_WAVES
+#define SPKD_MX_WAVES 4
+#endif
+constexpr int MX_WAVES = SPKD_MX_WAVES;
 
 // grid.x = total number of records; block g computes row a = g - seg_off[p] of
 // problem p = rec_prob[g]: D[a][c] for c > a (and D[c][a] for variant 1), plus the
@@ -425,7 +395,7 @@ __global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
     const int64_t N = seg_off[p + 1] - off;
     const int64_t ra = g - off;
     double* Dm = mat + mat_off[p];
-    const double* A = ex + g * REC;
+    const double* A = ex + g * QREC;
     stage_record(ldsA, A, threadIdx.x, MX_WAVES * WAVE);
     if (variant == 1) {
         if (threadIdx.x == 0) Dm[ra * N + ra] = MAXINT_F;
@@ -458,15 +428,15 @@ __global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
             for (int mi = 0; mi < 4; ++mi) {
                 int64_t c = base + mi;
                 c = c < N ? c : N - 1;
-                recs[mi] = ex + (off + c) * REC;
+                recs[mi] = ex + (off + c) * QREC;
                 selfs[mi] = false;
             }
             int64_t rc = base + L.m;
             const bool valid = rc < N;
             rc = valid ? rc : N - 1;
-            const double* C = ex + (off + rc) * REC;
+            const double* C = ex + (off + rc) * QREC;
             const double ldx = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, false, L, recs, selfs, err);
-            const double d = finish_distance(kind, lambdac, nA, ldA, rec_count(C), ld[off + rc], ldx);
+            const double d = finish_distance(kind, lambdac, nA, ldA, qr_count(C), ld[off + rc], ldx);
             if (valid && L.t == 0) {
                 Dm[ra * N + rc] = d;
                 if (variant == 1) Dm[rc * N + ra] = d;
@@ -505,6 +475,9 @@ __device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
 // column); a merge only invalidates the rows whose cached column was one of the
 // two merged clusters, so an iteration costs O(N) plus a few row rescans instead
 // of an O(N^2) scan, with numpy's first-occurrence / NaN semantics intact.
+#ifdef SPKD_PROFILE
+__device__ unsigned long long g_ahc_prof[8];      // profiling builds: rows rescanned, merges, 5 phase clocks of k_ahc
+#endif
 constexpr int NO_COL = 0x7fffffff;
 constexpr int AHC_MAX_N = 65536;       // records per problem (row-flag masks live in LDS)
 
@@ -567,6 +540,9 @@ __device__ __forceinline__ void refresh_rows(const double* __restrict__ Dm, long
                 nc = n2 < nc ? n2 : nc;
             }
             if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; dirty[r] = 0; }
+#ifdef SPKD_PROFILE
+            if (lane == 0) atomicAdd(&g_ahc_prof[0], 1ull);      // rows rescanned
+#endif
         }
     }
 }
@@ -609,10 +585,17 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     int n_merges = 0;
     const long long INF_IDX = 0x7fffffffffffffffLL;
     double fmin = 0.0;
+#ifdef SPKD_PROFILE
+    unsigned long long ahc_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull}, ahc_t = clock64();
+#define AHC_TICK(i) do { const unsigned long long now_ = clock64(); ahc_acc[i] += now_ - ahc_t; ahc_t = now_; } while (0)
+#else
+#define AHC_TICK(i) ((void)0)
+#endif
     while (true) {
         // ---- 0. refresh the cache of the rows a merge invalidated (wave per row)
         refresh_rows(Dm, N, al, dirty, rmin, rarg, rnan, s_masks, tid, wave, lane);
         __syncthreads();
+        AHC_TICK(0);
         // ---- 1. min / argmin over the alive sub-matrix, numpy semantics: first
         // occurrence in row-major order; any NaN -> min is NaN and argmin the first
         // NaN (distances.min(), distances.argmin(): CL1:203-204)
@@ -648,6 +631,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         fmin = mind;
         const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
         if (!go) break;
+        AHC_TICK(1);
         const long long r0 = index / N, c0 = index - r0 * N;
         if (r0 == c0) {                       // a diagonal cell won: degenerate
             if (tid == 0) atomicOr(err, ERR_DEGENERATE_MERGE);
@@ -663,8 +647,10 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             for (long long c = tid; c < sb; c += AHC_TPB) {
                 if (al[c]) { cb++; if (c < sa) ca++; }
             }
-            if (ca) atomicAdd(&s_cnt[0], ca);
-            if (cb) atomicAdd(&s_cnt[1], cb);
+#pragma unroll
+            for (int s = 1; s < WAVE; s <<= 1) { ca += __shfl_xor(ca, s); cb += __shfl_xor(cb, s); }
+            if (lane == 0 && ca) atomicAdd(&s_cnt[0], ca);
+            if (lane == 0 && cb) atomicAdd(&s_cnt[1], cb);
         }
         __syncthreads();
         if (tid == 0) {
@@ -675,25 +661,38 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         }
         n_merges++;
         m--;
+#ifdef SPKD_PROFILE
+        if (tid == 0) atomicAdd(&g_ahc_prof[1], 1ull);
+#endif
         // ---- 2. merge the statistics (speakers[a].extend(speakers[b]))
-        double* A = ex + (off + sa) * REC;
-        const double* B = ex + (off + sb) * REC;
-        stage_record_sum(ldsA, A, B, tid, AHC_TPB);       // the LDS image first (it reads A),
-        __syncthreads();
-        for (int e = tid; e < REC; e += AHC_TPB) A[e] = A[e] + B[e];    // then the record itself
-        __syncthreads();
-        // partner list (order is irrelevant: results are scattered by slot)
-        for (long long c = tid; c < N; c += AHC_TPB) {
-            if (c != sa && al[c]) ids[atomicAdd(&s_nids, 1)] = (int32_t)c;
+        double* A = ex + (off + sa) * QREC;
+        const double* B = ex + (off + sb) * QREC;
+        for (int e = tid; e < QREC; e += AHC_TPB) {
+            const double v = A[e] + B[e];
+            A[e] = v;
+            ldsA[e] = v;
         }
         __syncthreads();
+        // partner list (order is irrelevant: results are scattered by slot); one LDS atomic
+        // per wave and 64 slots, the lanes take their places from the ballot
+        for (long long c0 = 0; c0 < N; c0 += AHC_TPB) {
+            const long long c = c0 + tid;
+            const bool take = c < N && c != sa && al[c < N ? c : N - 1];
+            const unsigned long long mk = __ballot(take);
+            int base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&s_nids, __popcll(mk));
+            base = __shfl(base, 0);
+            if (take) ids[base + __popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)c;
+        }
+        __syncthreads();
+        AHC_TICK(2);
         const int nids = s_nids;
         const double nA = ldsA[QREC_COUNT_AT];
         // ---- 3. the merged cluster's own term and the log dets of its unions
         if (kind == SPKD_KL2) {
             if (wave == 0) {
                 double a[DA];
-                single_rows_from_packed(A, a);
+                single_rows_from_qr(A, a);
                 const double mean_i = a[D] / nA;
                 cov_rows(a, nA);
                 kl2_aux_from_cov(a, mean_i, aux + (off + sa) * AUX);
@@ -706,20 +705,21 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 for (int mi = 0; mi < 4; ++mi) {
                     int k = base + mi;
                     k = k < nids ? k : nids - 1;
-                    recs[mi] = ex + (off + ids[k]) * REC;
+                    recs[mi] = ex + (off + ids[k]) * QREC;
                     selfs[mi] = (k == 0);
                 }
                 int k = base + L.m;
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
                 const int32_t slot = ids[k];
-                const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * REC, k == 0, L, recs, selfs, err);
+                const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
                 if (valid && L.t == 0) {
                     if (k == 0) ldp[sa] = v; else tp[slot] = v;
                 }
             }
         }
         __syncthreads();
+        AHC_TICK(3);
         // ---- 4. finish the distances, update row (and column) sa and the row caches
         double wmax = __builtin_nan(""), wmin = __builtin_nan("");
         const double ldA = ldp[sa];
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 }
                 d = 0.5 * t1 + 0.5 * t2;
             } else {
-                const double nC = rec_count(ex + (off + c) * REC);
+                const double nC = qr_count(ex + (off + c) * QREC);
                 d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
             }
             Dm[sa * N + c] = d;
@@ -775,7 +775,11 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             }
         }
         __syncthreads();
+        AHC_TICK(4);
     }
+#ifdef SPKD_PROFILE
+    if (tid == 0) for (int i = 0; i < 5; ++i) atomicAdd(&g_ahc_prof[2 + i], ahc_acc[i]);
+#endif
     // max over the final alive sub-matrix (variant 2 reports distances.max()); NaN propagates
     double tmax = -__builtin_huge_val();
     bool anynan = false;
@@ -853,7 +857,7 @@ __device__ __forceinline__ double ahc_finish(int kind, double lambdac, const dou
         }
         return 0.5 * t1 + 0.5 * t2;
     }
-    const double nC = rec_count(ex + (off + c) * REC);
+    const double nC = qr_count(ex + (off + c) * QREC);
     return finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], ldx);
 }
 
@@ -1044,32 +1048,36 @@ __device__ __forceinline__ void ahc_select_body(
     }
     const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
     // compacted indices = alive slots in front; partner list (any order)
+    // (one LDS atomic per wave and 64 slots; the lanes take their places from the ballot --
+    // an atomic per alive cluster serialised ~4 000 LDS operations per merge on a 10 h file)
     {
         int ca = 0, cb = 0;
-        for (long long c = tid; c < N; c += AHC_TPB) {
-            if (!al[c]) continue;
-            if (c < sb) { cb++; if (c < sa) ca++; }
-            if (c != sa && c != sb) ids[atomicAdd(&s_nids, 1)] = (int32_t)c;
+        for (long long c0 = 0; c0 < N; c0 += AHC_TPB) {
+            const long long c = c0 + tid;
+            const bool alive_c = c < N && al[c < N ? c : N - 1];
+            if (alive_c && c < sb) { cb++; if (c < sa) ca++; }
+            const bool take = alive_c && c != sa && c != sb;
+            const unsigned long long mk = __ballot(take);
+            int base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&s_nids, __popcll(mk));
+            base = __shfl(base, 0);
+            if (take) ids[base + __popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)c;
         }
-        if (ca) atomicAdd(&s_cnt[0], ca);
-        if (cb) atomicAdd(&s_cnt[1], cb);
+        // (summed inside the wave first: one LDS atomic per wave, not per thread)
+#pragma unroll
+        for (int s = 1; s < WAVE; s <<= 1) { ca += __shfl_xor(ca, s); cb += __shfl_xor(cb, s); }
+        if (lane == 0 && ca) atomicAdd(&s_cnt[0], ca);
+        if (lane == 0 && cb) atomicAdd(&s_cnt[1], cb);
     }
     // ---- 2. merge the statistics
-    double* A = ex + (off + sa) * REC;
-    const double* B = ex + (off + sb) * REC;
-    double nA_new = 0.0;
-    for (int e = tid; e < REC; e += AHC_TPB) {
-        const double v = A[e] + B[e];
-        A[e] = v;
-        if (e == REC - 1) nA_new = v;                 // the merged frame count (thread (REC - 1) % TPB)
-    }
-    __shared__ double s_nA;
-    if (tid == (REC - 1) % AHC_TPB) s_nA = nA_new;
+    double* A = ex + (off + sa) * QREC;
+    const double* B = ex + (off + sb) * QREC;
+    for (int e = tid; e < QREC; e += AHC_TPB) A[e] = A[e] + B[e];
     __syncthreads();
-    const double nA = s_nA;
+    const double nA = A[QREC_COUNT_AT];
     if (kind == SPKD_KL2 && wave == 0) {
         double a[DA];
-        single_rows_from_packed(A, a);
+        single_rows_from_qr(A, a);
         const double mean_i = a[D] / nA;
         cov_rows(a, nA);
         kl2_aux_from_cov(a, mean_i, aux + (off + sa) * AUX);
@@ -1133,7 +1141,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
     const int32_t* ids = ids_all + off;
     const long long sa = S->sa, sb = S->sb;
     const double nA = S->nA;
-    const double* A = ex + (off + sa) * REC;
+    const double* A = ex + (off + sa) * QREC;
     double* Dm = mat + mat_off[p];
     int32_t* al = alive + off;
     double* ldp = ld + off;
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
     const int first = 1 + (int)blockIdx.x * RND_PARTNERS;
     const int mine = nids - first < RND_PARTNERS ? nids - first : RND_PARTNERS;     // partners here (>= 0)
     if (kind != SPKD_KL2) {
-        stage_record(ldsA, A, tid, AHC_TPB);
+        for (int e = tid; e < QREC; e += AHC_TPB) ldsA[e] = A[e];
         __syncthreads();
         const int base = 4 * wave;                  // items base .. base + 3 of this wave
         if (base <= mine) {
@@ -1157,13 +1165,13 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
                 int j = base + mi;
                 j = j <= mine ? j : mine;           // clamp to the last valid item (item 0 exists always)
                 item[mi] = j;
-                recs[mi] = j == 0 ? A : ex + (off + ids[first + j - 1]) * REC;
+                recs[mi] = j == 0 ? A : ex + (off + ids[first + j - 1]) * QREC;
                 selfs[mi] = (j == 0);
             }
             int j = base + L.m;
             const bool valid = j <= mine;
             j = valid ? j : mine;
-            const double* C = j == 0 ? A : ex + (off + ids[first + j - 1]) * REC;
+            const double* C = j == 0 ? A : ex + (off + ids[first + j - 1]) * QREC;
             const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, j == 0, L, recs, selfs, err);
             if (valid && L.t == 0) s_ldx[j] = v;
         }

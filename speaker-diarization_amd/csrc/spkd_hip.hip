@@ -352,11 +352,12 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     B.smin = B.smax + n_prob;
     HIPCHK(c, hipMemsetAsync(B.smax, 0x00, (size_t)n_prob * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(B.smin, 0xff, (size_t)n_prob * sizeof(unsigned long long), c->stream));
-    // a private working copy of the records (clusters are merged in place)
-    if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * REC * sizeof(double), &p)) != SPKD_OK) return st;
+    // a private working copy of the records (clusters are merged in place), expanded to the
+    // quad layout the clustering kernels load from
+    if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * QREC * sizeof(double), &p)) != SPKD_OK) return st;
     B.ex = (double*)p;
     if (n_total > 0)
-        HIPCHK(c, hipMemcpyAsync(B.ex, d_stats, (size_t)n_total * REC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_to_quadrec, dim3((unsigned)n_total), dim3(256), 0, c->stream, d_stats, n_total, B.ex);
     if (n_total > 0) {
         // KL2: one wave per record; BIC / GLR: four records per wave
         const int64_t per_block = kind == SPKD_KL2 ? PT_WAVES : 4 * PT_WAVES;
@@ -870,6 +871,13 @@ spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t* h_s
 #ifdef SPKD_PROFILE
 // profiling builds only: phase clocks of k_gw since the last call (cycles summed over
 // workgroups: prefix build, scan set-up, log-det jobs, finish + arg-max; scans; turns)
+extern "C" int spkd_debug_ahc_prof(unsigned long long* out4) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(spkd::g_ahc_prof), sizeof z) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(spkd::g_ahc_prof), z, sizeof z) != hipSuccess) return 1;
+    return 0;
+}
+
 extern "C" int spkd_debug_gw_prof(unsigned long long* out12) {
     unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(spkd::g_gw_prof), sizeof z) != hipSuccess) return 1;

@@ -79,4 +79,42 @@ __device__ __forceinline__ void quad_load_scaled(const double* __restrict__ qr, 
     }
 }
 
+
+// ===========================================================================
+// Tri records: the quad lane layout restricted to what the symmetric elimination reads,
+// in 128-byte lines: line (tri_off(s) + j) holds M(13 s + t, j) for t = 0..12 in its first
+// 13 doubles, j < 13 (s + 1); lines 78..80 hold the sums column of slot s; the frame count
+// sits in lane 15 of line 78.  81 lines = 10 368 B; every load of (slot s, column j) is one
+// aligned line per DPP row.
+// ===========================================================================
+constexpr int TLINES = 3 * QL + 3 * QL + 3;                  // 13 + 26 + 39 + 3 = 81
+constexpr int TREC = TLINES * 16;                            // 1 296 doubles = 10 368 B
+constexpr int TREC_SUMS = 6 * QL;                            // first sums line (78)
+constexpr int TREC_COUNT_AT = TREC_SUMS * 16 + 15;
+__host__ __device__ constexpr int tri_off(int s) { return s == 0 ? 0 : (s == 1 ? QL : 3 * QL); }
+
+// entry (row r, column j <= r) of the 40x40 augmented matrix -> index in a tri record
+__device__ __forceinline__ int tri_slot(int r, int j) {
+    if (r < D) { const int s = r / QL; return (tri_off(s) + j) * 16 + (r - QL * s); }
+    if (j < D) { const int s = j / QL; return (TREC_SUMS + s) * 16 + (j - QL * s); }
+    return TREC_COUNT_AT;
+}
+
+
+// tri-record index idx -> packed index holding the same entry (-1: padding)
+__device__ __forceinline__ int tri_image_source(int idx) {
+    const int t = idx & 15, line = idx >> 4;
+    if (line >= TREC_SUMS) {                     // sums lines: (39, 13 s + t), the count in lane 15 of the first
+        const int s = line - TREC_SUMS;
+        if (t < QL) return pk_low(D, QL * s + t);
+        return idx == TREC_COUNT_AT ? REC - 1 : -1;
+    }
+    if (t >= QL) return -1;
+    const int s = line < QL ? 0 : (line < 3 * QL ? 1 : 2);
+    const int j = line - tri_off(s);
+    const int r = QL * s + t;
+    return r >= j ? pk_low(r, j) : pk_low(j, r);
+}
+
+
 }  // namespace spkd

@@ -73,27 +73,94 @@ struct TriCol {
     }
 };
 
-// Step K.  The pivot a[K][K] was last written by the first column of step K - 1; the
-// remaining columns of that step (two instructions or more while K <= 36) separate that
-// write from the broadcast below, so only the first step (its source comes straight out
-// of the formation code) and the last two carry wait states of their own.
-// The smallest pivot is tracked instead of a per-step test: a pivot that is not a
-// positive finite number shows as pmin <= 0 or as a determinant that is NaN or infinite
-// (v_min_f64 drops a NaN operand, the product keeps it).
-template <int K>
-struct TriStep {
-    static __device__ __forceinline__ void run(QuadRows& q, double& det, double& pmin) {
-        if constexpr (K < D) {
-            constexpr int S = K / QL, T = K % QL;
-            const double piv = bcast16_nop<T, (K == 0 || K > 36)>(q.r[S][K]);
-            asm("v_min_f64 %0, %1, %2" : "=v"(pmin) : "v"(pmin), "v"(piv));    // (fmin() adds a canonicalisation)
-            det *= piv;
-            const double inv = fast_recip(piv);
-            double l[QS];
+// ---------------------------------------------------------------------------
+// The elimination with the pivot chain of step K + 1 interleaved into step K.
+//
+// Per step the multipliers need 1 / a[K][K]: a DPP broadcast, v_rcp_f64, two Newton steps,
+// then l_i = -a[i][K] / a[K][K] -- about nine dependent instructions, ~100 cycles of
+// latency in an in-order wave, 39 times per elimination.  The FMAs are opaque volatile
+// statements (their DPP form does not exist for the compiler), so the scheduler cannot
+// move that chain under them; left alone it sits between two steps and stalls the wave
+// (measured: a pass ran at 55 - 67 % of its issue bound).  Here the chain for pivot K + 1
+// starts as soon as column K + 1 of step K is final (it is updated first) and its
+// instructions are dealt out, as volatile statements of their own, between the remaining
+// column updates of step K, which do not depend on it.  Steps with too few columns left
+// run the rest of the chain back to back.
+//   op 0      piv = bcast a[P][P]            (its own s_nop: the FMA just before wrote it)
+//   op 1      r = rcp(piv)
+//   op 2, 3   Newton step  e = 1 - piv r ; r += e r
+//   op 4, 5   Newton step
+//   op 6..8   l_next[s] = -a[row of slot s][P] * r   (column P is final too)
+// The smallest pivot is tracked instead of a per-step test: a pivot that is not a positive
+// finite number shows as pmin <= 0 or as a determinant that is NaN or infinite (v_min_f64
+// drops a NaN operand, the product keeps it).
+// ---------------------------------------------------------------------------
+struct PivotChain {
+    double piv, r, e;
+};
+
+constexpr int CHAIN_OPS = 9;
+
+template <int P, int OP>
+__device__ __forceinline__ void chain_op(QuadRows& q, PivotChain& ch, double (&ln)[QS]) {
+    constexpr int S = P / QL, T = P % QL;
+    if constexpr (OP == 0) {
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "=v"(ch.piv) : "v"(q.r[S][P]), "n"(T));
+    } else if constexpr (OP == 1) {
+        asm volatile("v_rcp_f64 %0, %1" : "=v"(ch.r) : "v"(ch.piv));
+    } else if constexpr (OP == 2 || OP == 4) {
+        // (a transcendental result needs a wait state before a VALU read)
+        asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(ch.e) : "v"(ch.piv), "v"(ch.r));
+    } else if constexpr (OP == 3 || OP == 5) {
+        asm volatile("v_fma_f64 %0, %1, %0, %0" : "+v"(ch.r) : "v"(ch.e));
+    } else {
+        constexpr int s = OP - 6;
+        if constexpr (s >= S) asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(ln[s]) : "v"(q.r[s][P]), "v"(ch.r));
+        else ln[s] = 0.0;
+    }
+}
+
+template <int P, int OP>
+__device__ __forceinline__ void chain_rest(QuadRows& q, PivotChain& ch, double (&ln)[QS]) {
+    if constexpr (OP < CHAIN_OPS) {
+        chain_op<P, OP>(q, ch, ln);
+        chain_rest<P, OP + 1>(q, ch, ln);
+    }
+}
+
+// column J of step K (see TriCol), followed by the chain operations that are due
+template <int K, int J, int OP>
+struct TriColAhead {
+    static __device__ __forceinline__ void run(QuadRows& q, const double (&l)[QS], PivotChain& ch, double (&ln)[QS]) {
+        if constexpr (J < D) {
+            constexpr int SJ = J / QL, TJ = J % QL;
+            fmac_bcast16<TJ, false>(q.r[SJ][J], q.r[SJ][K], l[SJ]);
 #pragma unroll
-            for (int s = 0; s < QS; ++s) l[s] = (s >= S) ? -(q.r[s][K] * inv) : 0.0;
-            TriCol<K, K + 1>::run(q, l);
-            TriStep<K + 1>::run(q, det, pmin);
+            for (int s = SJ + 1; s < QS; ++s) fmac_bcast16<TJ, false>(q.r[s][J], q.r[SJ][K], l[s]);
+            constexpr int first = K + 1;                       // the column that holds the next pivot
+            constexpr int avail = D - 1 - first;               // columns behind it
+            constexpr int gap = avail >= 2 * CHAIN_OPS ? 2 : 1;
+            constexpr bool emit = OP < CHAIN_OPS && ((J - first) % gap == 0);
+            if constexpr (emit) chain_op<K + 1, OP>(q, ch, ln);
+            TriColAhead<K, J + 1, emit ? OP + 1 : OP>::run(q, l, ch, ln);
+        } else {
+            chain_rest<K + 1, OP>(q, ch, ln);                  // what did not fit between the columns
+        }
+    }
+};
+
+template <int K>
+struct TriStepAhead {
+    // l: multipliers of step K (ready); piv_k: its pivot (for the determinant)
+    static __device__ __forceinline__ void run(QuadRows& q, double& det, double& pmin, const double (&l)[QS], double piv_k) {
+        asm("v_min_f64 %0, %1, %2" : "=v"(pmin) : "v"(pmin), "v"(piv_k));    // (fmin() adds a canonicalisation)
+        det *= piv_k;
+        if constexpr (K + 1 < D) {
+            PivotChain ch;
+            double ln[QS];
+            TriColAhead<K, K + 1, 0>::run(q, l, ch, ln);
+            TriStepAhead<K + 1>::run(q, det, pmin, ln, ch.piv);
         }
     }
 };
@@ -103,7 +170,10 @@ struct TriStep {
 __device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out) {
     double det = 1.0;
     double pmin = __builtin_huge_val();
-    TriStep<0>::run(q, det, pmin);
+    PivotChain ch;
+    double l0[QS];
+    chain_rest<0, 0>(q, ch, l0);                               // the first pivot's chain: nothing to hide it under
+    TriStepAhead<0>::run(q, det, pmin, l0, ch.piv);
     det_out = det;
     return (pmin > 0.0) && (det == det) && (det < __builtin_huge_val());
 }

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'csrc', 'libspkd_hip.so')
+# (SPKD_HIP_LIBRARY: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get('SPKD_HIP_LIBRARY') or os.path.join(HERE, 'csrc', 'libspkd_hip.so')
 
 SPKD_OK, SPKD_EINVAL, SPKD_EHIP, SPKD_ENONFINITE, SPKD_EOVERFLOW, SPKD_ENOMEM = range(6)
 KINDS = {'BIC': 0, 'GLR': 1, 'KL2': 2}

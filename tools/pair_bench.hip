@@ -1,0 +1,127 @@
+// Where does a production pass lose time against the bare elimination?  BIC pair
+// distances of one row record (LDS) with a window of partner quad records (global):
+//   mode 0  the bare symmetric elimination (formation + tri_det_nopivot + log), as in
+//           blocked_bench.hip
+//   mode 1  the library's quad_pair_logdet<false> + finish_distance + the stores k_matrix does
+// each with the partner records L2-resident (n_rec = 387) and streaming from HBM
+// (n_rec = 40 000, every block a different window of 387 partners).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../speaker-diarization_amd/csrc -o pair_bench pair_bench.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "spkd_cluster.hpp"
+#include "spkd_tri.hpp"
+using namespace spkd;
+
+constexpr int WINDOW = 387;
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_pairs(const double* __restrict__ qr, int n_rec, const double* __restrict__ ld,
+                                               double* __restrict__ out, int* err) {
+    __shared__ double ldsA[QREC];
+    const int wave = threadIdx.x >> 6;
+    const QuadLane L = quad_lane();
+    const int a = (int)(((long long)blockIdx.x * 97) % n_rec);
+    const double* A = qr + (size_t)a * QREC;
+    for (int e = threadIdx.x; e < QREC; e += blockDim.x) ldsA[e] = A[e];
+    __syncthreads();
+    const double nA = ldsA[QREC_COUNT_AT];
+    const double ldA = ld[a];
+    double acc = 0.0;
+    for (int base = 4 * wave; base < WINDOW; base += 32) {
+        int w = base + L.m;
+        const bool valid = w < WINDOW;
+        w = valid ? w : WINDOW - 1;
+        const int rc = (a + 1 + w) % n_rec;
+        const double* C = qr + (size_t)rc * QREC;
+        if (MODE == 0) {
+            QuadRows q; double sv[QS];
+            int ta = L.t; asm volatile("" : "+v"(ta));
+            const double n = nA + C[QREC_COUNT_AT];
+            const double f = 1.0 / (n - 1.0);
+            const double* Ct = C + L.t;
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) q.r[s2][j] = Ct[(s2 * DA + j) * 16];
+                sv[s2] = Ct[(s2 * DA + D) * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double c1[QS];
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) q.r[s2][j] = f * (ldsA[(s2 * DA + j) * 16 + ta] + q.r[s2][j]);
+                sv[s2] = ldsA[(s2 * DA + D) * 16 + ta] + sv[s2];
+                c1[s2] = -((f / n) * sv[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TriRank1<0>::run(q, c1, sv);
+            double det; tri_det_nopivot(q, det);
+            acc += log(det);
+        } else {
+            const double* recs[4];
+            bool selfs[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                int c = base + mi; c = c < WINDOW ? c : WINDOW - 1;
+                recs[mi] = qr + (size_t)((a + 1 + c) % n_rec) * QREC;
+                selfs[mi] = false;
+            }
+            const double ldx = quad_pair_logdet<false>(SPKD_BIC, ldsA, nA, A, C, false, L, recs, selfs, err);
+            const double d = finish_distance(SPKD_BIC, 1.3, nA, ldA, qr_count(C), ld[rc], ldx);
+            if (valid && L.t == 0) out[(size_t)blockIdx.x * WINDOW + w] = d;
+            acc += d;
+        }
+    }
+    if (MODE == 0 && L.t == 0) out[(size_t)blockIdx.x * WINDOW + wave * 4 + L.m] = acc;
+}
+
+int main(int argc, char** argv) {
+    const int blocks = argc > 1 ? atoi(argv[1]) : 4096;
+    for (int n_rec : {387, 40000}) {
+        std::vector<double> h((size_t)n_rec * QREC, 0.0), hld(n_rec, 0.0);
+        srand(2);
+        std::vector<double> M(DA * DA);
+        for (int r = 0; r < n_rec; ++r) {
+            // a handful of generated records, repeated with a small perturbation of the counts
+            const int nf = 300 + (r % 7) * 100;
+            if (r < 64) {
+                std::fill(M.begin(), M.end(), 0.0);
+                for (int f = 0; f < nf; ++f) {
+                    double x[DA];
+                    for (int i = 0; i < D; ++i) x[i] = (rand() / (double)RAND_MAX) - 0.5 + 0.01 * r;
+                    x[D] = 1.0;
+                    for (int i = 0; i < DA; ++i) for (int j = 0; j < DA; ++j) M[j * DA + i] += x[i] * x[j];
+                }
+                double* o = &h[(size_t)r * QREC];
+                for (int i = 0; i < D; ++i) for (int j = 0; j < DA; ++j) o[qr_index(i, j)] = M[j * DA + i];
+                o[QREC_COUNT_AT] = nf;
+            } else {
+                std::copy(&h[(size_t)(r % 64) * QREC], &h[(size_t)(r % 64 + 1) * QREC], &h[(size_t)r * QREC]);
+            }
+            hld[r] = -30.0 - 0.01 * (r % 64);
+        }
+        double *dE, *dO, *dL; int* dErr;
+        hipMalloc(&dE, h.size() * 8); hipMalloc(&dO, (size_t)blocks * WINDOW * 8 + 4096); hipMalloc(&dL, n_rec * 8); hipMalloc(&dErr, 4);
+        hipMemcpy(dE, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        hipMemcpy(dL, hld.data(), n_rec * 8, hipMemcpyHostToDevice);
+        hipMemset(dErr, 0, 4);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int mode = 0; mode < 2; ++mode)
+            for (int it = 0; it < 3; ++it) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(k_pairs<0>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr);
+                else hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (it == 2) printf("n_rec %6d  %-34s %.3f ms  %.1f M pairs/s\n", n_rec,
+                                    mode == 0 ? "bare elimination" : "quad_pair_logdet + finish_distance", ms,
+                                    (double)blocks * WINDOW / ms / 1e3);
+            }
+        hipFree(dE); hipFree(dO); hipFree(dL); hipFree(dErr);
+    }
+    return 0;
+}
