@@ -328,6 +328,7 @@ def main():
                          'traffic_source': traffic_note},
             'kernels': per_kernel,
             'wall_ms': {k[5:]: round(float(np.mean(v)), 2) for k, v in timings.items() if k.startswith('wall_')},
+            'gw_stream_ms': round(avg('gw_stream_ms'), 2),
             'device_ms_per_step': round(sum(v[0] for v in kernels.values()) + avg('cluster_prep') + avg('reduce_sets'), 3),
             'verified': verified,
         }

@@ -17,6 +17,7 @@
 // Sliding window (not on the DIA2 path): prefix snapshots every SNAP_G frames and
 // the row-per-lane layout.
 #pragma once
+#include <type_traits>
 #include "spkd_device.hpp"
 #include "spkd_quad.hpp"
 #include "spkd_cluster.hpp"
@@ -357,16 +358,42 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
             SW_TICK(2);
         }
         const long long stop = want < tile_end ? want : tile_end;
-        const int f1 = (int)(stop - tile0);
+        const int f0 = (int)(pos - tile0), f1 = (int)(stop - tile0);
+        // the stretch between two coarse candidates is 12 or 13 frames: those run fully
+        // unrolled, all LDS reads in flight before the first FMA (one exposed LDS latency
+        // per stretch instead of one per group of four frames)
+        auto stretch = [&](auto nf) {
+            constexpr int NF = decltype(nf)::value;
+            float2 a[NF], b[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                a[f] = *reinterpret_cast<const float2*>(xi + (f0 + f) * DA);
+                b[f] = *reinterpret_cast<const float2*>(xj + (f0 + f) * DA);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const double a0 = (double)a[f].x, a1 = (double)a[f].y, b0 = (double)b[f].x, b1 = (double)b[f].y;
+                acc[0] = fma(a0, b0, acc[0]);
+                acc[1] = fma(a0, b1, acc[1]);
+                acc[2] = fma(a1, b0, acc[2]);
+                acc[3] = fma(a1, b1, acc[3]);
+            }
+        };
+        if (f1 - f0 == 13) {
+            stretch(std::integral_constant<int, 13>());
+        } else if (f1 - f0 == 12) {
+            stretch(std::integral_constant<int, 12>());
+        } else {
 #pragma unroll 4
-        for (int f = (int)(pos - tile0); f < f1; ++f) {
-            const float2 a = *reinterpret_cast<const float2*>(xi + f * DA);
-            const float2 b = *reinterpret_cast<const float2*>(xj + f * DA);
-            const double a0 = (double)a.x, a1 = (double)a.y, b0 = (double)b.x, b1 = (double)b.y;
-            acc[0] = fma(a0, b0, acc[0]);
-            acc[1] = fma(a0, b1, acc[1]);
-            acc[2] = fma(a1, b0, acc[2]);
-            acc[3] = fma(a1, b1, acc[3]);
+            for (int f = f0; f < f1; ++f) {
+                const float2 a = *reinterpret_cast<const float2*>(xi + f * DA);
+                const float2 b = *reinterpret_cast<const float2*>(xj + f * DA);
+                const double a0 = (double)a.x, a1 = (double)a.y, b0 = (double)b.x, b1 = (double)b.y;
+                acc[0] = fma(a0, b0, acc[0]);
+                acc[1] = fma(a0, b1, acc[1]);
+                acc[2] = fma(a1, b0, acc[2]);
+                acc[3] = fma(a1, b1, acc[3]);
+            }
         }
         pos = stop;
     }
@@ -505,7 +532,7 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
     }
 }
 
-// log det of four (pass, split point) items held by the wave: DPP row m forms the
+// determinant (its log is taken by the caller, densely) of four (pass, split point) items held by the wave: DPP row m forms the
 // matrix of ITS pass for ITS split b (packed cache record rec_b) -- the passes of a
 // scan are packed four to a wave whatever their kind, so `pass` is a per-lane value
 // and everything below is straight-line code with per-lane coefficients:
@@ -519,7 +546,7 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
 // two: the launch has GLR items (wave-uniform; the second rank-one term is skipped
 // otherwise).  DPP rows that name the same record (the left and the right item of a
 // new candidate sit side by side) fetch it once: their loads coalesce.
-__device__ __forceinline__ double quad_split_logdet(int pass, bool two, const double* ldsEnd,
+__device__ __forceinline__ double quad_split_det(int pass, bool two, const double* ldsEnd,
                                                     const double* __restrict__ rec_b,
                                                     double n1, double n2, const QuadLane& L, int* err) {
     QuadRows q;
@@ -594,7 +621,7 @@ __device__ __forceinline__ double quad_split_logdet(int pass, bool two, const do
         const double* rm = (const double*)__shfl((unsigned long long)rec_b, 16 * mi);
         single_split_matrix(__shfl(pass, 16 * mi), ldsEnd, rm, __shfl(n1, 16 * mi), __shfl(n2, 16 * mi), arr);
     };
-    return tri_logdet(q, L.m, err, form_single);
+    return tri_det(q, L.m, err, form_single);
 }
 
 // dynamic LDS: P(c) tri record | the sweep's persistent accumulators | float frame tile
@@ -603,8 +630,8 @@ constexpr int GW_LDS_BYTES = TREC * 8 + 4 * GW_TPB * 8 + GW_TILE * DA * 4;
 // Growing window over one VAD turn per workgroup (spk-change-detection.py:180-288):
 // the whole float state machine runs here; outputs are the per-window events.
 //
-// Candidate scratch per slot k: c_i = i value, c_left = memoised left term (BIC:
-// 0.5 N1 log det S1; GLR: log det S1), c_x = right log det / finished distance;
+// Candidate scratch per slot k: c_i = i value, c_left = determinant of the memoised left
+// covariance, c_x = determinant of the right one (KL2: the finished distance);
 // cache record k = P(b_k), a packed record.
 //
 // The kernel is one loop over "scans": a coarse scan over the candidates
@@ -859,12 +886,13 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 const double ik = count > 0 ? c_i[slot] : 0.0;
                 const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
                 const double n1 = (double)(b - a), n2 = (double)(c - b);
-                const double v = quad_split_logdet(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err);
+                // determinants; their logs are taken in phase (D), one thread per candidate
+                const double v = quad_split_det(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err);
                 if (valid && L.t == 0) {
                     if (pass == PASS_POOLED) s_ldS = v;
                     else if (pass == PASS_RIGHT) c_x[slot] = v;
-                    // left term, memoised per i inside an epoch (CD:84-90): BIC 0.5 N1 log det S1
-                    else if (pass == PASS_LEFT) c_left[slot] = glr_kind ? v : 0.5 * n1 * v;
+                    // left term, memoised per i inside an epoch (CD:84-90)
+                    else if (pass == PASS_LEFT) c_left[slot] = v;
                     else c_w[slot] = v;
                 }
             }
@@ -882,7 +910,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         BestD best;
         {
             const double N = (double)(c - a);
-            const double ldS = s_ldS;
+            const double ldS = kind == SPKD_BIC ? log(s_ldS) : 0.0;      // s_ldS, c_left, c_x, c_w hold determinants
             const double corr = pen_w * log(N);
             const int nw = S.nw;
             best.d = fine ? S.maxd : NEG_MAXINT_M1;
@@ -894,9 +922,10 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 const double n1 = (double)(b - a), n2 = (double)(c - b);
                 double d = c_x[slot];
                 if (kind == SPKD_GLR) {
-                    d = -(N / 2.0) * ((n1 / N) * c_left[slot] + (n2 / N) * d - c_w[slot]);
+                    d = -(N / 2.0) * ((n1 / N) * log(c_left[slot]) + (n2 / N) * log(d) - log(c_w[slot]));
                 } else if (kind == SPKD_BIC) {
-                    d = 0.5 * N * ldS - c_left[slot] - 0.5 * n2 * d;
+                    const double left = 0.5 * n1 * log(c_left[slot]);     // BIC's memoised 0.5 N1 log det S1
+                    d = 0.5 * N * ldS - left - 0.5 * n2 * log(d);
                     d -= corr;
                 }
                 if ((P.trace && !fine) || fabs(d) == __builtin_huge_val()) {

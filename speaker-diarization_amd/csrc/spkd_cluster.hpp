@@ -240,13 +240,22 @@ __device__ __forceinline__ void single_pair_matrix(int kind, const double* __res
 // allocation).
 // ldsA: quad record of cluster A staged in LDS (all four matrices share it);
 // gA: the same record in global memory (fallback path only).
+// pkC: the same partner record in the packed ABI layout (6 560 B) -- the hot loads read
+// that copy: by symmetry a packed record is the lower triangle column by column, so the
+// load of (slot s, column j) is 13 consecutive doubles at pk_off(j) + 13 s - j + t (lanes of
+// a diagonal block above the diagonal read the previous column's tail: inside the record,
+// into registers nobody reads).  A pass of the merge loop streams its partners from HBM
+// (a problem's records exceed its share of L2): tools/pair_bench.hip, partners streaming,
+// 559 M pairs/s from quad records, 686 M pairs/s from packed ones.  The quad copy (qrC)
+// serves the rare pivoting fallback and the in-place merges' LDS staging.
 template <bool TWO>
-__device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA, double nA,
+__device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, double nA,
                                                    const double* __restrict__ gA,
-                                                   const double* __restrict__ qrC, bool self,
+                                                   const double* __restrict__ qrC,
+                                                   const double* __restrict__ pkC, bool self,
                                                    const QuadLane& L, const double* const* qrC_by_m,
                                                    const bool* self_by_m, int* err) {
-    const double nC = self ? 0.0 : qr_count(qrC);
+    const double nC = self ? 0.0 : pkC[REC - 1];
     const double n = nA + nC;
     const bool glr = TWO && (kind == SPKD_GLR && !self);
     // (an IEEE fp64 division is ~25 instructions; the covariance scale uses the Newton
@@ -262,16 +271,29 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
             k2 = -(wc / nC);
         }
     }
-    const double* Ct = qrC + L.t;
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keeps A's LDS reads inside the caller's loop
     QuadRows q;
     double sc[QS];
+    {
+        // 81 loads in flight, one latency; one base pointer per 4 KB of the record (the
+        // immediate offset of a global load spans 4 KB)
+        const int t12 = ta < QL ? ta : QL - 1;          // idle lanes 13..15 ride with lane 12
+        const double* rt[2];
+        long long o1 = 512;                 // opaque, so that the bases stay separate registers
+        asm volatile("" : "+v"(o1));
+        rt[0] = pkC + t12;
+        rt[1] = rt[0] + o1;
 #pragma unroll
-    for (int s = 0; s < QS; ++s) {        // 81 loads in flight, one latency
+        for (int s = 0; s < QS; ++s) {
 #pragma unroll
-        for (int j = 0; j < tri_cols(s); ++j) q.r[s][j] = Ct[(s * DA + j) * 16];
-        sc[s] = Ct[(s * DA + D) * 16];
+            for (int j = 0; j < tri_cols(s); ++j) {
+                const int e = pk_off(j) + QL * s - j;   // + t12 (in the base)
+                q.r[s][j] = rt[e / 512][e % 512];
+            }
+            const int c = QL * s + t12;                 // this lane's row of slot s
+            sc[s] = pkC[pk_off(c) + D - c];             // (39, c): the sums entry of column c
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     double v1[QS], v2[QS], c1[QS], c2[QS];
@@ -293,7 +315,7 @@ __device__ __forceinline__ double quad_pair_logdet(int kind, const double* ldsA,
     auto form_single = [&](int mi, double (&a)[DA]) {
         single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
     };
-    return tri_logdet(q, L.m, err, form_single);
+    return tri_det(q, L.m, err, form_single);
 }
 
 __device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
@@ -383,8 +405,8 @@ constexpr int MX_WAVES = SPKD_MX_WAVES;
 // eliminations -- with one eight-wave block per CU the SIMDs idled through both.
 template <bool TWO>
 __global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
-        const double* __restrict__ ex, const int64_t* __restrict__ seg_off, const int32_t* __restrict__ rec_prob,
-        int variant, int kind, double lambdac,
+        const double* __restrict__ ex, const double* __restrict__ pk, const int64_t* __restrict__ seg_off,
+        const int32_t* __restrict__ rec_prob, int variant, int kind, double lambdac,
         const double* __restrict__ ld, const double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
@@ -435,8 +457,9 @@ __global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
             const bool valid = rc < N;
             rc = valid ? rc : N - 1;
             const double* C = ex + (off + rc) * QREC;
-            const double ldx = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, false, L, recs, selfs, err);
-            const double d = finish_distance(kind, lambdac, nA, ldA, qr_count(C), ld[off + rc], ldx);
+            const double* Cp = pk + (off + rc) * REC;
+            const double ldx = log(quad_pair_det<TWO>(kind, ldsA, nA, A, C, Cp, false, L, recs, selfs, err));
+            const double d = finish_distance(kind, lambdac, nA, ldA, Cp[REC - 1], ld[off + rc], ldx);
             if (valid && L.t == 0) {
                 Dm[ra * N + rc] = d;
                 if (variant == 1) Dm[rc * N + ra] = d;
@@ -549,7 +572,7 @@ __device__ __forceinline__ void refresh_rows(const double* __restrict__ Dm, long
 
 template <bool TWO>
 __global__ __launch_bounds__(AHC_TPB) void k_ahc(
-        double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        double* __restrict__ ex, double* __restrict__ pk, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double lambdac, double threshold,
         double* __restrict__ ld, double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
@@ -672,6 +695,11 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             A[e] = v;
             ldsA[e] = v;
         }
+        {                                             // the packed copies the pair passes load from
+            double* Ap = pk + (off + sa) * REC;
+            const double* Bp = pk + (off + sb) * REC;
+            for (int e = tid; e < REC; e += AHC_TPB) Ap[e] = Ap[e] + Bp[e];
+        }
         __syncthreads();
         // partner list (order is irrelevant: results are scattered by slot); one LDS atomic
         // per wave and 64 slots, the lanes take their places from the ballot
@@ -712,9 +740,10 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
                 const int32_t slot = ids[k];
-                const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, k == 0, L, recs, selfs, err);
+                // determinants: the partners' logs are taken in step 4, one thread per partner
+                const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, pk + (off + slot) * REC, k == 0, L, recs, selfs, err);
                 if (valid && L.t == 0) {
-                    if (k == 0) ldp[sa] = v; else tp[slot] = v;
+                    if (k == 0) ldp[sa] = log(v); else tp[slot] = v;
                 }
             }
         }
@@ -740,7 +769,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 d = 0.5 * t1 + 0.5 * t2;
             } else {
                 const double nC = qr_count(ex + (off + c) * QREC);
-                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], tp[c]);
+                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[c], log(tp[c]));
             }
             Dm[sa * N + c] = d;
             const int ra = rarg[c], rn = rnan[c];
@@ -934,7 +963,7 @@ __device__ __forceinline__ void ahc_select_body(
         int32_t* __restrict__ rcache_all, int32_t* __restrict__ ids_all,
         AhcState* __restrict__ state, int32_t* __restrict__ out_a, int32_t* __restrict__ out_b,
         double* __restrict__ out_d, unsigned long long* stat_max, unsigned long long* stat_min,
-        int* err) {
+        int* err, double* __restrict__ pk) {
     struct RowRed { double mv, wmax, wmin; int mc, nc; };
     __shared__ RowRed rred[AHC_WAVES];
     __shared__ ArgMin red[AHC_WAVES];
@@ -1073,6 +1102,11 @@ __device__ __forceinline__ void ahc_select_body(
     double* A = ex + (off + sa) * QREC;
     const double* B = ex + (off + sb) * QREC;
     for (int e = tid; e < QREC; e += AHC_TPB) A[e] = A[e] + B[e];
+    {                                                 // the packed copies the pair passes load from
+        double* Ap = pk + (off + sa) * REC;
+        const double* Bp = pk + (off + sb) * REC;
+        for (int e = tid; e < REC; e += AHC_TPB) Ap[e] = Ap[e] + Bp[e];
+    }
     __syncthreads();
     const double nA = A[QREC_COUNT_AT];
     if (kind == SPKD_KL2 && wave == 0) {
@@ -1096,7 +1130,7 @@ __device__ __forceinline__ void ahc_select_body(
 
 // the first selection of every problem (grid: n_prob)
 __global__ __launch_bounds__(AHC_TPB) void k_ahc_select0(
-        double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        double* __restrict__ ex, double* __restrict__ pk, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double threshold, double* __restrict__ aux,
         const double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         int32_t* __restrict__ alive, double* __restrict__ rmin_all,
@@ -1106,7 +1140,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_select0(
         int* err) {
     if (threadIdx.x == 0) state[blockIdx.x].ticket = 0;
     ahc_select_body(0, blockIdx.x, ex, seg_off, variant, kind, max_spk, threshold, aux, mat, mat_off, alive,
-                    rmin_all, rcache_all, ids_all, state, out_a, out_b, out_d, stat_max, stat_min, err);
+                    rmin_all, rcache_all, ids_all, state, out_a, out_b, out_d, stat_max, stat_min, err, pk);
 }
 
 // partners per workgroup: every wave pass holds four matrices; the first slot of the
@@ -1116,7 +1150,7 @@ constexpr int RND_PARTNERS = 4 * AHC_WAVES - 1;
 // one merge round; grid (ceil((n_max - 1) / RND_PARTNERS), n_prob)
 template <bool TWO>
 __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
-        int it, double* __restrict__ ex, const int64_t* __restrict__ seg_off,
+        int it, double* __restrict__ ex, double* __restrict__ pk, const int64_t* __restrict__ seg_off,
         int variant, int kind, int max_spk, double lambdac, double threshold,
         double* __restrict__ ld, double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
@@ -1171,19 +1205,20 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
             int j = base + L.m;
             const bool valid = j <= mine;
             j = valid ? j : mine;
-            const double* C = j == 0 ? A : ex + (off + ids[first + j - 1]) * QREC;
-            const double v = quad_pair_logdet<TWO>(kind, ldsA, nA, A, C, j == 0, L, recs, selfs, err);
-            if (valid && L.t == 0) s_ldx[j] = v;
+            const long long cs = j == 0 ? sa : (long long)ids[first + j - 1];
+            const double* C = ex + (off + cs) * QREC;
+            const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, C, pk + (off + cs) * REC, j == 0, L, recs, selfs, err);
+            if (valid && L.t == 0) s_ldx[j] = v;          // determinants
         }
         __syncthreads();
     }
-    const double ldA = kind == SPKD_KL2 ? 0.0 : s_ldx[0];
+    const double ldA = kind == SPKD_KL2 ? 0.0 : log(s_ldx[0]);
     if (kind != SPKD_KL2 && blockIdx.x == 0 && tid == 0) ldp[sa] = ldA;      // the merged cluster's cached term
     // ---- finish this workgroup's distances, row / column sa, the partner rows' caches
     // (a wave per row: a row whose cached minimum was invalidated is rescanned at once)
     for (int j = 1 + wave; j <= mine; j += AHC_WAVES) {
         const long long r = ids[first + j - 1];
-        const double d = ahc_finish(kind, lambdac, ex, aux, ldp, kind == SPKD_KL2 ? 0.0 : s_ldx[j], off, sa, r, nA, ldA);
+        const double d = ahc_finish(kind, lambdac, ex, aux, ldp, kind == SPKD_KL2 ? 0.0 : log(s_ldx[j]), off, sa, r, nA, ldA);
         const int ra = rarg[r], rn = rnan[r];
         const double rm = rmin[r];
         double mv;
@@ -1227,7 +1262,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
     __syncthreads();
     if (!s_last) return;
     ahc_select_body(it, p, ex, seg_off, variant, kind, max_spk, threshold, aux, mat, mat_off, alive,
-                    rmin_all, rcache_all, ids_all, state, out_a, out_b, out_d, stat_max, stat_min, err);
+                    rmin_all, rcache_all, ids_all, state, out_a, out_b, out_d, stat_max, stat_min, err, pk);
 }
 
 __global__ __launch_bounds__(AHC_TPB) void k_ahc_final(

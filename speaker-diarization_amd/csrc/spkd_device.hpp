@@ -281,7 +281,9 @@ constexpr int ERR_NONFINITE = 1;
 // instructions each; inlining the rarely taken ones at every call site blows the
 // kernels far past the instruction cache (k_gw was > 500 KB of code), so they are
 // real functions, emitted once per code object, taking the row array by pointer.
-__device__ __noinline__ double logdet_pivoted_fn(const double* rows, int* err) {
+// determinant by partial pivoting (NaN + the error bit for non-finite input); its log,
+// taken by the caller, is what scipy.linalg.det + numpy.log give: 0 -> -inf, negative -> NaN
+__device__ __noinline__ double det_pivoted_fn(const double* rows, int* err) {
     double a[DA];
 #pragma unroll
     for (int j = 0; j < DA; ++j) a[j] = rows[j];
@@ -289,7 +291,11 @@ __device__ __noinline__ double logdet_pivoted_fn(const double* rows, int* err) {
         if (lane_id() == 0) atomicOr(err, ERR_NONFINITE);
         return __builtin_nan("");
     }
-    return log(det_pivoted(a));
+    return det_pivoted(a);
+}
+
+__device__ __forceinline__ double logdet_pivoted_fn(const double* rows, int* err) {
+    return log(det_pivoted_fn(rows, err));
 }
 
 template <class Form>

@@ -20,7 +20,7 @@
 using namespace spkd;
 
 namespace {
-constexpr int N_SLOTS = 25;
+constexpr int N_SLOTS = 26;
 }
 
 struct spkd_ctx {
@@ -121,7 +121,7 @@ spkd_status end_call(spkd_ctx* c) {
 enum {
     S_CHUNKS = 0, S_SETOFF, S_PARTIAL, S_IDXA, S_IDXB, S_TERMS, S_TURNS, S_SNAP, S_CAND,
     S_EV_I32A, S_EV_I32B, S_EV_D0, S_EV_D1, S_EV_D2, S_EV_D3, S_EV_D4, S_LOG,
-    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB
+    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB, S_AHC_PACKED
 };
 
 }  // namespace
@@ -307,6 +307,7 @@ spkd_status spkd_pair_terms(spkd_ctx* c, const double* d_stats, const int32_t* h
 namespace {
 struct AhcBuffers {
     double* ex;
+    double* pk;          // packed working copies (the pair passes load these)
     double* ld;
     double* aux;
     double* mat;
@@ -356,8 +357,12 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     // quad layout the clustering kernels load from
     if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * QREC * sizeof(double), &p)) != SPKD_OK) return st;
     B.ex = (double*)p;
-    if (n_total > 0)
+    if ((st = scratch(c, S_AHC_PACKED, (size_t)n_total * REC * sizeof(double), &p)) != SPKD_OK) return st;
+    B.pk = (double*)p;
+    if (n_total > 0) {
         hipLaunchKernelGGL(k_to_quadrec, dim3((unsigned)n_total), dim3(256), 0, c->stream, d_stats, n_total, B.ex);
+        HIPCHK(c, hipMemcpyAsync(B.pk, d_stats, (size_t)n_total * REC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     if (n_total > 0) {
         // KL2: one wave per record; BIC / GLR: four records per wave
         const int64_t per_block = kind == SPKD_KL2 ? PT_WAVES : 4 * PT_WAVES;
@@ -368,7 +373,7 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
         auto kmat = kind == SPKD_GLR ? k_matrix<true> : k_matrix<false>;   // GLR has a second rank-one term
         TIMED(c, SPKD_T_MATRIX,
               hipLaunchKernelGGL(kmat, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
-                                 (const double*)B.ex, (const int64_t*)B.seg_off, (const int32_t*)d_prob, variant, kind, lambdac,
+                                 (const double*)B.ex, (const double*)B.pk, (const int64_t*)B.seg_off, (const int32_t*)d_prob, variant, kind, lambdac,
                                  (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
                                  B.smax, B.smin, c->d_err));
     }
@@ -455,7 +460,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
             (void)hipFuncSetAttribute((const void*)kahc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         TIMED(c, SPKD_T_AHC,
               hipLaunchKernelGGL(kahc, dim3((unsigned)n_prob), dim3(AHC_TPB), lds, c->stream,
-                                 B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
+                                 B.ex, B.pk, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                                  P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
                                  d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
     } else {
@@ -466,7 +471,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
                            (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off, d_alive,
                            d_rmin, d_rcache);
         hipLaunchKernelGGL(k_ahc_select0, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
-                           B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->threshold, B.aux,
+                           B.ex, B.pk, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->threshold, B.aux,
                            (const double*)B.mat, (const int64_t*)B.mat_off, d_alive, d_rmin, d_rcache, d_ids,
                            d_state, d_a, d_b, d_merge_d, B.smax, B.smin, c->d_err);
         // round `it` finishes merge `it` (its distances, row caches) and selects merge it + 1;
@@ -475,7 +480,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
             const int64_t partners = n_max - it - 1;
             const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + RND_PARTNERS - 1) / RND_PARTNERS);
             hipLaunchKernelGGL(kround, dim3(blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
-                               (int)it, B.ex, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk,
+                               (int)it, B.ex, B.pk, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk,
                                P->lambdac, P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive,
                                d_rmin, d_rcache, d_ids, d_state, d_a, d_b, d_merge_d, B.smax, B.smin, c->d_err);
         }

@@ -192,15 +192,17 @@ struct TriRank1 {
     }
 };
 
-// log(det) of the four lower triangles held in q (per lane: its own matrix).
+// det of the four lower triangles held in q (per lane: its own matrix).
 // Matrices that meet a pivot that is not a positive finite number (this is also how
 // NaN / inf entries surface) are redone one at a time in the row-per-lane layout
 // with partial pivoting: form_single(mi, a) must fill matrix mi there.
+// The LOG is left to the caller: a wave holds four determinants, so a log taken here costs
+// a full instruction sequence per four values; the kernels take it later, in their dense
+// one-thread-per-candidate phases (same value, same rounding).
 template <class FormSingle>
-__device__ __forceinline__ double tri_logdet(QuadRows& q, int m, int* err, FormSingle form_single) {
+__device__ __forceinline__ double tri_det(QuadRows& q, int m, int* err, FormSingle form_single) {
     double det;
     const bool ok = tri_det_nopivot(q, det);
-    double ld = log(det);
     const unsigned long long badmask = __ballot(!ok);
     if (badmask) {
 #pragma unroll 1
@@ -208,11 +210,16 @@ __device__ __forceinline__ double tri_logdet(QuadRows& q, int m, int* err, FormS
             if (((badmask >> (16 * mi)) & 0xffffull) == 0ull) continue;   // wave-uniform
             double a[DA];
             form_single(mi, a);
-            const double v = logdet_pivoted_fn(a, err);
-            if (m == mi) ld = v;
+            const double v = det_pivoted_fn(a, err);
+            if (m == mi) det = v;
         }
     }
-    return ld;
+    return det;
+}
+
+template <class FormSingle>
+__device__ __forceinline__ double tri_logdet(QuadRows& q, int m, int* err, FormSingle form_single) {
+    return log(tri_det(q, m, err, form_single));
 }
 
 }  // namespace spkd

@@ -82,6 +82,7 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     _t2 = time.perf_counter()
     if timings is not None:
         timings.setdefault('gw', []).append(ctx.last_ms('gw'))
+        timings.setdefault('gw_stream_ms', []).append(ctx.last_ms('call'))     # uploads + kernel + result copies
         timings['gw_frames'] = int((te - tb).sum())
         timings['gw_windows'] = int(r['n_win'].sum())
     if r['status'] == hipabi.SPKD_ENONFINITE:

@@ -19,7 +19,7 @@ constexpr int WINDOW = 387;
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k_pairs(const double* __restrict__ qr, int n_rec, const double* __restrict__ ld,
-                                               double* __restrict__ out, int* err) {
+                                               double* __restrict__ out, int* err, const double* __restrict__ pk = nullptr) {
     __shared__ double ldsA[QREC];
     const int wave = threadIdx.x >> 6;
     const QuadLane L = quad_lane();
@@ -36,7 +36,38 @@ __global__ __launch_bounds__(512) void k_pairs(const double* __restrict__ qr, in
         w = valid ? w : WINDOW - 1;
         const int rc = (a + 1 + w) % n_rec;
         const double* C = qr + (size_t)rc * QREC;
-        if (MODE == 0) {
+        if (MODE == 2) {
+            // bare elimination, partner records in the packed ABI layout (6 560 B)
+            const double* P = pk + (size_t)rc * REC;
+            QuadRows q; double sv[QS];
+            int ta = L.t; asm volatile("" : "+v"(ta));
+            const double n = nA + P[REC - 1];
+            const double f = 1.0 / (n - 1.0);
+            const int t12 = ta < QL ? ta : QL - 1;
+            const double* rt[2];
+            long long o1 = 512; asm volatile("" : "+v"(o1));
+            rt[0] = P + t12; rt[1] = rt[0] + o1;
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) { const int e = pk_off(j) + QL * s2 - j; q.r[s2][j] = rt[e / 512][e % 512]; }
+                const int c = QL * s2 + t12;
+                sv[s2] = P[pk_off(c) + D - c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double c1[QS];
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) q.r[s2][j] = f * (ldsA[(s2 * DA + j) * 16 + ta] + q.r[s2][j]);
+                sv[s2] = ldsA[(s2 * DA + D) * 16 + ta] + sv[s2];
+                c1[s2] = -((f / n) * sv[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TriRank1<0>::run(q, c1, sv);
+            double det; tri_det_nopivot(q, det);
+            acc += log(det);
+        } else if (MODE == 0) {
             QuadRows q; double sv[QS];
             int ta = L.t; asm volatile("" : "+v"(ta));
             const double n = nA + C[QREC_COUNT_AT];
@@ -70,13 +101,13 @@ __global__ __launch_bounds__(512) void k_pairs(const double* __restrict__ qr, in
                 recs[mi] = qr + (size_t)((a + 1 + c) % n_rec) * QREC;
                 selfs[mi] = false;
             }
-            const double ldx = quad_pair_logdet<false>(SPKD_BIC, ldsA, nA, A, C, false, L, recs, selfs, err);
+            const double ldx = log(quad_pair_det<false>(SPKD_BIC, ldsA, nA, A, C, pk + (size_t)rc * REC, false, L, recs, selfs, err));
             const double d = finish_distance(SPKD_BIC, 1.3, nA, ldA, qr_count(C), ld[rc], ldx);
             if (valid && L.t == 0) out[(size_t)blockIdx.x * WINDOW + w] = d;
             acc += d;
         }
     }
-    if (MODE == 0 && L.t == 0) out[(size_t)blockIdx.x * WINDOW + wave * 4 + L.m] = acc;
+    if (MODE != 1 && L.t == 0) out[(size_t)blockIdx.x * WINDOW + wave * 4 + L.m] = acc;
 }
 
 int main(int argc, char** argv) {
@@ -104,24 +135,39 @@ int main(int argc, char** argv) {
             }
             hld[r] = -30.0 - 0.01 * (r % 64);
         }
-        double *dE, *dO, *dL; int* dErr;
+        // packed copies of the same records
+        std::vector<double> hp((size_t)n_rec * REC, 0.0);
+        for (int r = 0; r < n_rec; ++r) {
+            const double* o = &h[(size_t)r * QREC];
+            double* pr = &hp[(size_t)r * REC];
+            for (int j = 0; j < DA; ++j) for (int i = j; i < DA; ++i) {
+                double v;
+                if (i < D) v = o[qr_index(i, j)];
+                else if (j < D) v = o[qr_index(j, D)];     // sums
+                else v = o[QREC_COUNT_AT];
+                pr[pk_off(j) + (i - j)] = v;
+            }
+        }
+        double *dE, *dO, *dL, *dP; int* dErr;
+        hipMalloc(&dP, hp.size() * 8); hipMemcpy(dP, hp.data(), hp.size() * 8, hipMemcpyHostToDevice);
         hipMalloc(&dE, h.size() * 8); hipMalloc(&dO, (size_t)blocks * WINDOW * 8 + 4096); hipMalloc(&dL, n_rec * 8); hipMalloc(&dErr, 4);
         hipMemcpy(dE, h.data(), h.size() * 8, hipMemcpyHostToDevice);
         hipMemcpy(dL, hld.data(), n_rec * 8, hipMemcpyHostToDevice);
         hipMemset(dErr, 0, 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int mode = 0; mode < 2; ++mode)
+        for (int mode = 0; mode < 3; ++mode)
             for (int it = 0; it < 3; ++it) {
                 hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(k_pairs<0>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr);
-                else hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr);
+                if (mode == 0) hipLaunchKernelGGL(k_pairs<0>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)nullptr);
+                else if (mode == 1) hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)dP);
+                else hipLaunchKernelGGL(k_pairs<2>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)dP);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (it == 2) printf("n_rec %6d  %-34s %.3f ms  %.1f M pairs/s\n", n_rec,
-                                    mode == 0 ? "bare elimination" : "quad_pair_logdet + finish_distance", ms,
+                                    mode == 0 ? "bare elimination" : (mode == 1 ? "quad_pair_det + log + finish_distance" : "bare elimination, packed records"), ms,
                                     (double)blocks * WINDOW / ms / 1e3);
             }
-        hipFree(dE); hipFree(dO); hipFree(dL); hipFree(dErr);
+        hipFree(dP); hipFree(dE); hipFree(dO); hipFree(dL); hipFree(dErr);
     }
     return 0;
 }
