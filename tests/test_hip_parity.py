@@ -323,3 +323,41 @@ def test_sliding_window_and_merge_modes_on_a_longer_file(eng, tmp_path):
         outs[tag] = res
     assert outs['hip'] == outs['orc']
     assert outs['hip'][0].count('\n') > len(vad)
+
+
+def test_non_finite_covariance_raises_like_the_reference_but_writes_nothing(eng, tmp_path):
+    """A NaN frame makes a covariance non-finite: scipy.linalg.det raises ValueError in the
+    reference at the offending call, i.e. AFTER the lines of earlier turns were written and
+    earlier `Merging:` lines printed.  The library reports it per launch: the same
+    ValueError is raised, but nothing of the file group the launch covered is written or
+    printed (documented deviation; failure path only)."""
+    import io
+    synth = pkg('synth')
+    cli = pkg('cli')
+    feats, vad, _ = synth.make_session(4242, 150, 3)
+    bad = feats.copy()
+    a, b = vad[len(vad) // 2]
+    bad[(a + b) // 2, 7] = np.nan                  # inside a turn in the middle of the file
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'x.fea'), bad)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(synth.vad_recipe_text('x.wav', vad))
+    out = os.path.join(tmp, 'spkc.recipe')
+    said = io.StringIO()
+    with pytest.raises(ValueError, match='infs or NaNs'):
+        cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), os.path.join(tmp, 'fea') + '/', '-o', out,
+                                   '-m', 'gw', '-d', 'BIC', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0'],
+                                  engine=eng, stdout=said)
+    assert not os.path.exists(out) or open(out).read() == ''
+    # clustering: a recipe of clean turns plus one that covers the NaN frame
+    good = os.path.join(tmp, 'turns.recipe')
+    with open(good, 'w') as f:
+        for k, (s, e) in enumerate(vad):
+            f.write('audio=x.wav lna=a_%d start-time=%s end-time=%s speaker=spk_turn\n' % (
+                k + 1, repr(s / 125.0), repr(e / 125.0)))
+    said = io.StringIO()
+    with pytest.raises(ValueError, match='infs or NaNs'):
+        cli.main_clustering([good, os.path.join(tmp, 'fea') + '/', '-o', os.path.join(tmp, 'out.recipe'),
+                             '-m', 'hi', '-l', '1.3'], variant=1, engine=eng, stdout=said)
+    assert 'Merging:' not in said.getvalue()

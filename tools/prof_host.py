@@ -8,7 +8,7 @@ import runpy
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-extras'] + sys.argv[1:]
 sys.path.insert(0, ROOT)
 pr = cProfile.Profile()
 pr.enable()
