@@ -62,6 +62,9 @@ def parse():
                     help='distinct synthetic sessions (0 = every file its own; fewer are tiled)')
     ap.add_argument('--seconds', type=float, default=3600.0)
     ap.add_argument('--speakers', type=int, default=4)
+    ap.add_argument('--streams', type=int, default=1,
+                    help='host threads, each with its own library context (a stream of its own) and an '
+                         'equal share of the files: the host work of one share overlaps the kernels of another')
     ap.add_argument('--two-pass', action='store_true',
                     help='read the frames once per stage (k_chunk_stats) instead of the fused single read')
     ap.add_argument('--cpu-sample-seconds', type=float, default=900.0)
@@ -212,8 +215,46 @@ def main():
     fused = not args.two_pass
     cl = dict(pipeline.DIA2_CL, path=args.ahc_path)
 
+    # optional: several host threads, each driving its share of the files through its own
+    # context (ctypes and numpy release the GIL; the library is thread-safe per context)
+    n_streams = max(1, min(args.streams, args.files))
+    shares = [list(range(k, args.files, n_streams)) for k in range(n_streams)]
+    ctxs = [ctx] + [hipabi.Context(local) for _ in range(n_streams - 1)]
+
+    def run_share(k, tm):
+        sub = [files[i] for i in shares[k]]
+        return pipeline.diarize_batch(ctxs[k], ptr, total, sub, cl=cl, timings=tm, fused=fused)
+
     def step(tm=None):
-        rows = pipeline.diarize_batch(ctx, ptr, total, files, cl=cl, timings=tm, fused=fused)
+        if n_streams == 1:
+            rows = pipeline.diarize_batch(ctx, ptr, total, files, cl=cl, timings=tm, fused=fused)
+        else:
+            import threading
+            parts = [None] * n_streams
+            tms = [({} if tm is not None else None) for _ in range(n_streams)]
+
+            def work(k):
+                parts[k] = run_share(k, tms[k])
+
+            th = [threading.Thread(target=work, args=(k,)) for k in range(1, n_streams)]
+            for t_ in th:
+                t_.start()
+            work(0)
+            for t_ in th:
+                t_.join()
+            rows = [None] * args.files
+            for k in range(n_streams):
+                for i, r in zip(shares[k], parts[k]):
+                    rows[i] = r
+            if tm is not None:                     # kernel times: sums over the shares (they overlap in time)
+                for k in range(n_streams):
+                    for key, v in tms[k].items():
+                        if isinstance(v, list):
+                            tm.setdefault(key, [])
+                            if len(tm[key]) < len(tms[0].get(key, v)) or k == 0:
+                                tm[key] = [a + b for a, b in zip(tm[key], v)] if (k > 0 and len(tm[key]) == len(v)) else list(v)
+                        else:
+                            tm[key] = tm.get(key, 0) + v if k > 0 else v
         if world == 1:
             return {i: r for i, r in enumerate(rows)}
         # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)
@@ -322,7 +363,8 @@ def main():
                        'files_per_gpu': args.files, 'frames_per_file': int(T),
                        'segments_per_step': n_sets,
                        'segments_recomputed_from_frames': timings.get('stats_recomputed', n_sets),
-                       'parallelism': 'file-sharded x%d, no data-path collective' % world},
+                       'parallelism': 'file-sharded x%d, no data-path collective' % world,
+                       'host_threads_per_gpu': n_streams},
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_source': traffic_note},

@@ -248,6 +248,29 @@ spkd_status spkd_ahc(spkd_ctx *ctx, const double *d_stats, const int64_t *h_seg_
                      double *h_merge_d, double *h_stat_max, double *h_stat_min);
 
 /* ---------------------------------------------------------------------------
+ * (6) Feature front-end: what `feacat -c fconfig.cfg -H --raw-output x.wav` computes for the
+ * reference (spk-diarization2.py:98-100; external AaltoASR C++, not in the reference tree)
+ * with the module chain of fconfig.cfg:1-101: pre-emphasis, 400-sample Hamming windows at
+ * 125 frames/s, magnitude spectrum, mel filterbank + log, DCT (12 cepstra) and log power,
+ * mean subtraction over +-75 frames, deltas and delta-deltas, normalization, 39x39
+ * transform.  PARITY UNPINNED: feacat is not available, the semantics the configuration
+ * file leaves open are documented choices (oracle/mfcc_numpy.py).
+ * d_pcm: n_samples 16-bit mono samples in device memory; the caller passes the tables
+ * (host): mel filterbank [21][257], DCT [12][21], mean[39], scale[39], transform[39][39].
+ * d_features receives floor(n_samples / hop) frames of 39 floats (*h_n_frames). */
+typedef struct {
+    int32_t sample_rate, frame_rate, window_width, n_fft, n_mel, n_cep;
+    int32_t cms_left, cms_right;
+    int32_t delta_width[2];
+    float pre_emph;
+    float delta_norm[2];
+} spkd_mfcc_params;
+spkd_status spkd_mfcc(spkd_ctx *ctx, const int16_t *d_pcm, int64_t n_samples,
+                      const spkd_mfcc_params *params, const float *h_melfb, const float *h_dct,
+                      const float *h_mean, const float *h_scale, const float *h_transform,
+                      float *d_features, int64_t *h_n_frames);
+
+/* ---------------------------------------------------------------------------
  * (5) Host-side helpers of the boundary (no GPU work).
  *
  * spkd_py2_roundtrip: v[i] <- float(str(v[i])) with Python-2 str() = "%.12g":

@@ -16,11 +16,12 @@
 #include "spkd_cluster.hpp"
 #include "spkd_device.hpp"
 #include "spkd_stats.hpp"
+#include "spkd_mfcc.hpp"
 
 using namespace spkd;
 
 namespace {
-constexpr int N_SLOTS = 26;
+constexpr int N_SLOTS = 28;
 }
 
 struct spkd_ctx {
@@ -121,7 +122,7 @@ spkd_status end_call(spkd_ctx* c) {
 enum {
     S_CHUNKS = 0, S_SETOFF, S_PARTIAL, S_IDXA, S_IDXB, S_TERMS, S_TURNS, S_SNAP, S_CAND,
     S_EV_I32A, S_EV_I32B, S_EV_D0, S_EV_D1, S_EV_D2, S_EV_D3, S_EV_D4, S_LOG,
-    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB, S_AHC_PACKED
+    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB, S_AHC_PACKED, S_MFCC_TAB, S_MFCC_STATIC
 };
 
 }  // namespace
@@ -737,6 +738,57 @@ spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if (n_d > 0)
         HIPCHK(c, hipMemcpyAsync(h_d, d_out, (size_t)n_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return end_call(c);
+}
+
+// ------------------------------------------------------------------ (6) front-end
+spkd_status spkd_mfcc(spkd_ctx* c, const int16_t* d_pcm, int64_t n_samples, const spkd_mfcc_params* P,
+                      const float* h_melfb, const float* h_dct, const float* h_mean, const float* h_scale,
+                      const float* h_transform, float* d_features, int64_t* h_n_frames) {
+    if (!c || !P || !h_n_frames) return SPKD_EINVAL;
+    *h_n_frames = 0;
+    if (n_samples < 0 || !h_melfb || !h_dct || !h_mean || !h_scale || !h_transform)
+        return fail(c, SPKD_EINVAL, "mfcc: null argument");
+    if (P->window_width != MF_WIN || P->n_fft != MF_NFFT || P->n_mel != MF_MEL || P->n_cep != MF_CEP ||
+        P->frame_rate <= 0 || P->sample_rate % P->frame_rate != 0)
+        return fail(c, SPKD_EINVAL, "mfcc: this build does 400-sample windows, a 512-point transform, 21 mel bins, 12 cepstra");
+    if (P->cms_left < 0 || P->cms_right < 0 || P->cms_left + P->cms_right > 1024 || P->delta_width[0] < 1 ||
+        P->delta_width[0] > 2 || P->delta_width[1] < 1 || P->delta_width[1] > 2 || !(P->delta_norm[0] > 0.f) ||
+        !(P->delta_norm[1] > 0.f))
+        return fail(c, SPKD_EINVAL, "mfcc: unsupported mean-subtraction window or delta parameters");
+    const int hop = P->sample_rate / P->frame_rate;
+    const int64_t T = n_samples / hop;
+    *h_n_frames = T;
+    if (T == 0) return SPKD_OK;
+    if (!d_pcm || !d_features) return fail(c, SPKD_EINVAL, "mfcc: null device buffer");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    // tables: mel filterbank | dct | mean | scale | transform
+    std::vector<float> tab;
+    tab.insert(tab.end(), h_melfb, h_melfb + MF_MEL * MF_BINS);
+    tab.insert(tab.end(), h_dct, h_dct + MF_CEP * MF_MEL);
+    tab.insert(tab.end(), h_mean, h_mean + MF_DIM);
+    tab.insert(tab.end(), h_scale, h_scale + MF_DIM);
+    tab.insert(tab.end(), h_transform, h_transform + MF_DIM * MF_DIM);
+    float* d_tab = nullptr;
+    void* d_static = nullptr;
+    if ((st = upload(c, S_MFCC_TAB, tab, &d_tab)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_MFCC_STATIC, (size_t)T * MF_STATIC * sizeof(float), &d_static)) != SPKD_OK) return st;
+    const float* d_fb = d_tab;
+    const float* d_dct = d_fb + MF_MEL * MF_BINS;
+    const float* d_mean = d_dct + MF_CEP * MF_MEL;
+    const float* d_scale = d_mean + MF_DIM;
+    const float* d_tr = d_scale + MF_DIM;
+    hipLaunchKernelGGL(k_mfcc_static, dim3((unsigned)((T + MF_FR - 1) / MF_FR)), dim3(MF_TPB), 0, c->stream,
+                       d_pcm, (long long)n_samples, (long long)T, hop, P->pre_emph, d_fb, d_dct, (float*)d_static);
+    const int span = MP_FR + 2 * MP_HALO;
+    const size_t lds = (size_t)((span + P->cms_left + P->cms_right) * MF_STATIC + 2 * span * MF_STATIC +
+                                MP_FR * MF_DIM + MF_DIM * MF_DIM) * sizeof(float);
+    if (lds > 60 * 1024) return fail(c, SPKD_EINVAL, "mfcc: mean-subtraction window too wide for the LDS tile");
+    hipLaunchKernelGGL(k_mfcc_post, dim3((unsigned)((T + MP_FR - 1) / MP_FR)), dim3(MF_TPB), lds, c->stream,
+                       (const float*)d_static, (long long)T, P->cms_left, P->cms_right, P->delta_width[0],
+                       P->delta_norm[0], P->delta_width[1], P->delta_norm[1], d_mean, d_scale, d_tr, d_features);
+    HIPCHK(c, hipGetLastError());
+    return end_call(c);        // (tab must outlive the upload: end_call waits for the stream)
 }
 
 // ------------------------------------------------------------------ (5) host helpers

@@ -20,7 +20,7 @@ DIM = 39
 EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
            'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
-           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats',
+           'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats', 'spkd_mfcc',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
            'spkd_labels_from_merges', 'spkd_labels_from_merges_batch']
 
@@ -38,6 +38,13 @@ class CandLog(C.Structure):
 
 
 AHC_AUTO, AHC_MONO, AHC_WIDE = 0, 1, 2
+
+
+class MfccParams(C.Structure):
+    _fields_ = [('sample_rate', C.c_int32), ('frame_rate', C.c_int32), ('window_width', C.c_int32),
+                ('n_fft', C.c_int32), ('n_mel', C.c_int32), ('n_cep', C.c_int32), ('cms_left', C.c_int32),
+                ('cms_right', C.c_int32), ('delta_width', C.c_int32 * 2), ('pre_emph', C.c_float),
+                ('delta_norm', C.c_float * 2)]
 
 
 class AhcParams(C.Structure):
@@ -93,6 +100,7 @@ def load_library(path=None):
     lib.spkd_gw_fused.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, C.c_int, vp, vp, vp, vp, vp, vp,
                                   vp, vp, vp, i64, P(i64)]
     lib.spkd_gather_stats.argtypes = [vp, vp, i64, vp, vp, i64, i64, vp]
+    lib.spkd_mfcc.argtypes = [vp, vp, i64, P(MfccParams), vp, vp, vp, vp, vp, vp, P(i64)]
     lib.spkd_sw_window_count.argtypes = [i64, dbl, dbl]
     lib.spkd_sw_window_count.restype = i64
     lib.spkd_sw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp]
@@ -330,6 +338,14 @@ class Context(object):
                               C.byref(params), _ptr(off), _ptr(d))
         self.check(st, allow=(SPKD_ENONFINITE,))
         return st, off, d
+
+    # ---- (6)
+    def mfcc(self, d_pcm, n_samples, params, melfb, dct, mean, scale, transform, d_features):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (melfb, dct, mean, scale, transform)]
+        n = C.c_int64(0)
+        self.check(self.lib.spkd_mfcc(self.h, C.c_void_p(d_pcm), n_samples, C.byref(params), *[_ptr(a) for a in arrs],
+                                      C.c_void_p(d_features), C.byref(n)))
+        return int(n.value)
 
     # ---- (4)
     def ahc(self, d_stats, seg_off, params):

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/feaconfig.json: the PARAMETERS of the reference's feature
+configuration (fconfig.cfg:1-101) as parsed by speaker-diarization_amd/feaconfig.py.
+Runs only where /root/reference exists; the configuration file itself is not copied."""
+import importlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+REF = os.environ.get('SPKD_REFERENCE', '/root/reference')
+
+
+def main():
+    fc = importlib.import_module('speaker-diarization_amd.feaconfig')
+    cfg = fc.FeatureConfig.load(os.path.join(REF, 'fconfig.cfg'))
+    d = dict(sample_rate=cfg.sample_rate, frame_rate=cfg.frame_rate, window_width=cfg.window_width,
+             pre_emph=cfg.pre_emph, copy_borders=cfg.copy_borders, magnitude=cfg.magnitude, n_cep=cfg.n_cep,
+             zeroth=cfg.zeroth, cms_left=cfg.cms_left, cms_right=cfg.cms_right, delta_width=cfg.delta_width,
+             delta_norm=cfg.delta_norm, dim=cfg.dim, mean=[float(x) for x in cfg.mean],
+             scale=[float(x) for x in cfg.scale], transform=[float(x) for x in cfg.transform.ravel()],
+             source="parameters parsed from the reference's fconfig.cfg:1-101 by speaker-diarization_amd/feaconfig.py "
+                    "(tests/golden/make_golden_feaconfig.py); the file itself is not copied")
+    with open(os.path.join(HERE, 'feaconfig.json'), 'w') as f:
+        json.dump(d, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
