@@ -551,6 +551,7 @@ __device__ __forceinline__ double quad_split_det(int pass, bool two, const doubl
                                                     double n1, double n2, const QuadLane& L, int* err) {
     QuadRows q;
     double svb[QS];
+    PASS_T0();
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keep the LDS reads out of the callers' loops
     const double n = n1 + n2;
@@ -602,6 +603,7 @@ __device__ __forceinline__ double quad_split_det(int pass, bool two, const doubl
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    PASS_LOADED();
     double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -621,7 +623,9 @@ __device__ __forceinline__ double quad_split_det(int pass, bool two, const doubl
         const double* rm = (const double*)__shfl((unsigned long long)rec_b, 16 * mi);
         single_split_matrix(__shfl(pass, 16 * mi), ldsEnd, rm, __shfl(n1, 16 * mi), __shfl(n2, 16 * mi), arr);
     };
-    return tri_det(q, L.m, err, form_single);
+    const double det = tri_det(q, L.m, err, form_single);
+    PASS_DONE();
+    return det;
 }
 
 // dynamic LDS: P(c) tri record | the sweep's persistent accumulators | float frame tile
@@ -702,6 +706,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
 
 #ifdef SPKD_PROFILE
     unsigned long long prof_acc[4] = {0ull, 0ull, 0ull, 0ull}, prof_t = clock64(), prof_scans = 0ull;
+    unsigned long long prof_passes = 0ull, prof_items = 0ull;
 #endif
     for (int e = tid; e < TREC; e += GW_TPB) ldsEnd[e] = 0.0;
     // record 0 is read (times zero) by the pooled item even before it is built
@@ -873,7 +878,13 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 }
                 return true;
             };
+#ifdef SPKD_PROFILE
+            prof_items += (unsigned long long)M;
+#endif
             for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
+#ifdef SPKD_PROFILE
+                ++prof_passes;
+#endif
                 long long it = 4 * q4 + L.m;
                 bool valid = it < M;
                 it = valid ? it : M - 1;
@@ -1064,7 +1075,9 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         for (int i = 0; i < 4; ++i) atomicAdd(&g_gw_prof[i], prof_acc[i]);
         atomicAdd(&g_gw_prof[4], prof_scans);
         atomicAdd(&g_gw_prof[5], 1ull);
+        atomicAdd(&g_gw_prof[7], prof_items);
     }
+    if (lane == 0) atomicAdd(&g_gw_prof[6], prof_passes);
 #endif
 }
 

@@ -248,13 +248,26 @@ __device__ __forceinline__ void single_pair_matrix(int kind, const double* __res
 // (a problem's records exceed its share of L2): tools/pair_bench.hip, partners streaming,
 // 559 M pairs/s from quad records, 686 M pairs/s from packed ones.  The quad copy (qrC)
 // serves the rare pivoting fallback and the in-place merges' LDS staging.
+#ifdef SPKD_PROFILE
+// profiling builds: cycles a wave waits for a pass's record loads, cycles of whole passes, passes
+__device__ unsigned long long g_pass_prof[4];
+#define PASS_T0() const unsigned long long pass_t0_ = clock64()
+#define PASS_LOADED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long pass_t1_ = clock64()
+#define PASS_DONE() do { if (lane_id() == 0 && ((pass_t0_ >> 4) & 63) == 0) { const unsigned long long pass_t2_ = clock64(); /* 1 pass in 64 */ \
+        atomicAdd(&g_pass_prof[0], pass_t1_ - pass_t0_); atomicAdd(&g_pass_prof[1], pass_t2_ - pass_t0_); \
+        atomicAdd(&g_pass_prof[2], 1ull); } } while (0)
+#else
+#define PASS_T0() ((void)0)
+#define PASS_LOADED() ((void)0)
+#define PASS_DONE() ((void)0)
+#endif
+
 template <bool TWO>
 __device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, double nA,
                                                    const double* __restrict__ gA,
                                                    const double* __restrict__ qrC,
                                                    const double* __restrict__ pkC, bool self,
-                                                   const QuadLane& L, const double* const* qrC_by_m,
-                                                   const bool* self_by_m, int* err) {
+                                                   const QuadLane& L, int* err) {
     const double nC = self ? 0.0 : pkC[REC - 1];
     const double n = nA + nC;
     const bool glr = TWO && (kind == SPKD_GLR && !self);
@@ -275,6 +288,7 @@ __device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, do
     asm volatile("" : "+v"(ta));          // keeps A's LDS reads inside the caller's loop
     QuadRows q;
     double sc[QS];
+    PASS_T0();
     {
         // 81 loads in flight, one latency; one base pointer per 4 KB of the record (the
         // immediate offset of a global load spans 4 KB)
@@ -296,6 +310,7 @@ __device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, do
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    PASS_LOADED();
     double v1[QS], v2[QS], c1[QS], c2[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -313,9 +328,14 @@ __device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, do
     TriRank1<0>::run(q, c1, v1);
     if constexpr (TWO) TriRank1<0>::run(q, c2, v2);
     auto form_single = [&](int mi, double (&a)[DA]) {
-        single_pair_matrix(kind, gA, qrC_by_m[mi], self_by_m[mi], a);
+        // (the record and the flag of DPP row mi, from its first lane: no per-pass arrays,
+        // which live in scratch and cost 2.3 KB of stores per wave pass)
+        const double* rm = (const double*)__shfl((unsigned long long)qrC, 16 * mi);
+        single_pair_matrix(kind, gA, rm, __shfl((int)self, 16 * mi) != 0, a);
     };
-    return tri_det(q, L.m, err, form_single);
+    const double det = tri_det(q, L.m, err, form_single);
+    PASS_DONE();
+    return det;
 }
 
 __device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
@@ -397,8 +417,9 @@ __device__ __forceinline__ int find_problem(const int64_t* __restrict__ seg_off,
 #endif
 constexpr int MX_WAVES = SPKD_MX_WAVES;
 
-// grid.x = total number of records; block g computes row a = g - seg_off[p] of
-// problem p = rec_prob[g]: D[a][c] for c > a (and D[c][a] for variant 1), plus the
+// One block per record, in the launch order `sched` (XCD-aware, built by the host: the
+// rows of a problem run on one XCD); block b computes row a = g - seg_off[p] of problem
+// p = rec_prob[g], g = sched[b]: D[a][c] for c > a (and D[c][a] for variant 1), plus the
 // diagonal / lower-triangle initial values.  Each wave evaluates four partners per pass.
 // Four waves per block, two blocks per CU: a block's start-up (staging its row's record,
 // a dependent chain of global loads) and its ragged end overlap with the other block's
@@ -406,12 +427,13 @@ constexpr int MX_WAVES = SPKD_MX_WAVES;
 template <bool TWO>
 __global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
         const double* __restrict__ ex, const double* __restrict__ pk, const int64_t* __restrict__ seg_off,
-        const int32_t* __restrict__ rec_prob, int variant, int kind, double lambdac,
+        const int32_t* __restrict__ rec_prob, const int32_t* __restrict__ sched, int variant, int kind, double lambdac,
         const double* __restrict__ ld, const double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
     __shared__ double ldsA[QREC];
-    const int64_t g = blockIdx.x;
+    const int64_t g = sched[blockIdx.x];
+    if (g < 0) return;                       // (padding of the launch order: block-uniform)
     const int p = rec_prob[g];
     const int64_t off = seg_off[p];
     const int64_t N = seg_off[p + 1] - off;
@@ -444,21 +466,12 @@ __global__ __launch_bounds__(MX_WAVES * WAVE, 2) void k_matrix(
         }
     } else {
         for (int64_t base = ra + 1 + 4 * wave; base < N; base += 4 * MX_WAVES) {
-            const double* recs[4];
-            bool selfs[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                int64_t c = base + mi;
-                c = c < N ? c : N - 1;
-                recs[mi] = ex + (off + c) * QREC;
-                selfs[mi] = false;
-            }
             int64_t rc = base + L.m;
             const bool valid = rc < N;
             rc = valid ? rc : N - 1;
             const double* C = ex + (off + rc) * QREC;
             const double* Cp = pk + (off + rc) * REC;
-            const double ldx = log(quad_pair_det<TWO>(kind, ldsA, nA, A, C, Cp, false, L, recs, selfs, err));
+            const double ldx = log(quad_pair_det<TWO>(kind, ldsA, nA, A, C, Cp, false, L, err));
             const double d = finish_distance(kind, lambdac, nA, ldA, Cp[REC - 1], ld[off + rc], ldx);
             if (valid && L.t == 0) {
                 Dm[ra * N + rc] = d;
@@ -727,21 +740,12 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             }
         } else {
             for (int base = 4 * wave; base < nids; base += 4 * AHC_WAVES) {
-                const double* recs[4];
-                bool selfs[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    int k = base + mi;
-                    k = k < nids ? k : nids - 1;
-                    recs[mi] = ex + (off + ids[k]) * QREC;
-                    selfs[mi] = (k == 0);
-                }
                 int k = base + L.m;
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
                 const int32_t slot = ids[k];
                 // determinants: the partners' logs are taken in step 4, one thread per partner
-                const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, pk + (off + slot) * REC, k == 0, L, recs, selfs, err);
+                const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, ex + (off + slot) * QREC, pk + (off + slot) * REC, k == 0, L, err);
                 if (valid && L.t == 0) {
                     if (k == 0) ldp[sa] = log(v); else tp[slot] = v;
                 }
@@ -1191,23 +1195,12 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
         __syncthreads();
         const int base = 4 * wave;                  // items base .. base + 3 of this wave
         if (base <= mine) {
-            const double* recs[4];
-            bool selfs[4];
-            int item[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                int j = base + mi;
-                j = j <= mine ? j : mine;           // clamp to the last valid item (item 0 exists always)
-                item[mi] = j;
-                recs[mi] = j == 0 ? A : ex + (off + ids[first + j - 1]) * QREC;
-                selfs[mi] = (j == 0);
-            }
             int j = base + L.m;
             const bool valid = j <= mine;
             j = valid ? j : mine;
             const long long cs = j == 0 ? sa : (long long)ids[first + j - 1];
             const double* C = ex + (off + cs) * QREC;
-            const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, C, pk + (off + cs) * REC, j == 0, L, recs, selfs, err);
+            const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, C, pk + (off + cs) * REC, j == 0, L, err);
             if (valid && L.t == 0) s_ldx[j] = v;          // determinants
         }
         __syncthreads();

@@ -335,6 +335,41 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     prob_of.assign((size_t)n_total, 0);              // record -> its problem
     for (int64_t p = 0; p < n_prob; ++p)
         for (int64_t r = h_seg_off[p]; r < h_seg_off[p + 1]; ++r) prob_of[(size_t)r] = (int32_t)p;
+    // k_matrix's launch order, appended to the same upload: block b computes the matrix row
+    // of record sched[b] (-1: nothing).  Workgroups go to the eight XCDs round-robin by block
+    // index and every XCD has an L2 of its own, so the rows of one problem -- they all read
+    // that problem's records as partners -- are given to ONE XCD: its working set is then a
+    // problem or two (2.5 MB each at N = 390) instead of a slice of all of them.  Whole
+    // problems are dealt to the least-loaded XCD, largest first; with fewer problems than
+    // XCDs the rows are dealt round-robin instead.
+    int64_t grid_rows = 0;
+    {
+        const int X = 8;
+        std::vector<std::vector<int32_t>> lists(X);
+        if (n_prob >= X) {
+            std::vector<int64_t> order((size_t)n_prob);
+            for (int64_t p = 0; p < n_prob; ++p) order[(size_t)p] = p;
+            std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+                return h_seg_off[a + 1] - h_seg_off[a] > h_seg_off[b + 1] - h_seg_off[b];
+            });
+            double load[X] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t p : order) {
+                int x = 0;
+                for (int i = 1; i < X; ++i) if (load[i] < load[x]) x = i;
+                const double n = (double)(h_seg_off[p + 1] - h_seg_off[p]);
+                load[x] += n * n;
+                for (int64_t r = h_seg_off[p]; r < h_seg_off[p + 1]; ++r) lists[x].push_back((int32_t)r);
+            }
+        } else {
+            for (int64_t r = 0; r < n_total; ++r) lists[(size_t)(r % X)].push_back((int32_t)r);
+        }
+        size_t longest = 0;
+        for (auto& l : lists) longest = std::max(longest, l.size());
+        grid_rows = (int64_t)longest * X;
+        prob_of.resize((size_t)(n_total + grid_rows), -1);
+        for (int x = 0; x < X; ++x)
+            for (size_t i = 0; i < lists[x].size(); ++i) prob_of[(size_t)n_total + i * X + x] = lists[x][i];
+    }
     int64_t* d_offs = nullptr;
     int32_t* d_prob = nullptr;
     spkd_status st;
@@ -373,8 +408,9 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
                                  (const double*)B.ex, n_total, kind, B.ld, B.aux, c->d_err));
         auto kmat = kind == SPKD_GLR ? k_matrix<true> : k_matrix<false>;   // GLR has a second rank-one term
         TIMED(c, SPKD_T_MATRIX,
-              hipLaunchKernelGGL(kmat, dim3((unsigned)n_total), dim3(MX_WAVES * WAVE), 0, c->stream,
-                                 (const double*)B.ex, (const double*)B.pk, (const int64_t*)B.seg_off, (const int32_t*)d_prob, variant, kind, lambdac,
+              hipLaunchKernelGGL(kmat, dim3((unsigned)grid_rows), dim3(MX_WAVES * WAVE), 0, c->stream,
+                                 (const double*)B.ex, (const double*)B.pk, (const int64_t*)B.seg_off, (const int32_t*)d_prob,
+                                 (const int32_t*)d_prob + n_total, variant, kind, lambdac,
                                  (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
                                  B.smax, B.smin, c->d_err));
     }
@@ -932,6 +968,13 @@ extern "C" int spkd_debug_ahc_prof(unsigned long long* out4) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(spkd::g_ahc_prof), sizeof z) != hipSuccess) return 1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(spkd::g_ahc_prof), z, sizeof z) != hipSuccess) return 1;
+    return 0;
+}
+
+extern "C" int spkd_debug_pass_prof(unsigned long long* out4) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(spkd::g_pass_prof), sizeof z) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(spkd::g_pass_prof), z, sizeof z) != hipSuccess) return 1;
     return 0;
 }
 

@@ -76,63 +76,92 @@ struct TriCol {
 // ---------------------------------------------------------------------------
 // The elimination with the pivot chain of step K + 1 interleaved into step K.
 //
-// Per step the multipliers need 1 / a[K][K]: a DPP broadcast, v_rcp_f64, two Newton steps,
+// Per step the multipliers need 1 / a[K][K]: a DPP broadcast, v_rcp_f64, Newton steps,
 // then l_i = -a[i][K] / a[K][K] -- about nine dependent instructions, ~100 cycles of
 // latency in an in-order wave, 39 times per elimination.  The FMAs are opaque volatile
 // statements (their DPP form does not exist for the compiler), so the scheduler cannot
 // move that chain under them; left alone it sits between two steps and stalls the wave
 // (measured: a pass ran at 55 - 67 % of its issue bound).  Here the chain for pivot K + 1
 // starts as soon as column K + 1 of step K is final (it is updated first) and its
-// instructions are dealt out, as volatile statements of their own, between the remaining
-// column updates of step K, which do not depend on it.  Steps with too few columns left
-// run the rest of the chain back to back.
-//   op 0      piv = bcast a[P][P]            (its own s_nop: the FMA just before wrote it)
-//   op 1      r = rcp(piv)
-//   op 2, 3   Newton step  e = 1 - piv r ; r += e r
-//   op 4, 5   Newton step
+// instructions are dealt out between the remaining column updates of step K, which do
+// not depend on it.  Steps with too few columns left run the rest of the chain back to back.
+//   op 0      piv = bcast a[P][P]                       (inline asm: a DPP move)
+//   op 1      det *= pivot of the CURRENT step, sign |= its sign bit
+//   op 2      r = rcp(piv)
+//   op 3..5   one cubic refinement step (below)
 //   op 6..8   l_next[s] = -a[row of slot s][P] * r   (column P is final too)
-// The smallest pivot is tracked instead of a per-step test: a pivot that is not a positive
-// finite number shows as pmin <= 0 or as a determinant that is NaN or infinite (v_min_f64
-// drops a NaN operand, the product keeps it).
+// Ops 1..8 are ordinary C++ pinned in place by scheduling barriers, NOT inline asm: the
+// compiler's hazard recogniser counts an inline-asm statement as zero wait states and
+// assumes the worst of it, so every asm statement that reads a register written by an
+// earlier asm statement with nothing but asm in between gets an s_nop in front (gfx950's
+// dst-forwarding rule) -- as asm the chain cost ~400 such s_nop per elimination, 2.7
+// cycles of issue each.  A compiler-visible instruction between two asm statements ends
+// that look-back, which is also why op 1 sits between the broadcast and the rcp.
+// A pivot that is not a positive finite number shows in the OR of the pivots' sign bits, or
+// as a determinant that is NaN or infinite (a zero pivot gives an infinite reciprocal).
 // ---------------------------------------------------------------------------
 struct PivotChain {
     double piv, r, e;
 };
 
-constexpr int CHAIN_OPS = 9;
+// 1 / pivot: v_rcp_f64 is good to 4.6e-8 (tools/rcp_precision.hip); one cubic step
+//     e = 1 - piv r ;  t = e + e^2 ;  r += r t         (r (1 + e + e^2), error e^3 ~ 1e-22)
+// brings it to the last bit in three FMAs (two quadratic Newton steps take four).
+constexpr int NEWTON_OPS = 3;
+constexpr int CHAIN_OPS = 3 + NEWTON_OPS + QS;
+
+struct DetAcc {
+    double det;
+    int sign;          // OR of the high words of the pivots
+};
 
 template <int P, int OP>
-__device__ __forceinline__ void chain_op(QuadRows& q, PivotChain& ch, double (&ln)[QS]) {
+__device__ __forceinline__ void chain_op(QuadRows& q, PivotChain& ch, double (&ln)[QS], DetAcc& da, double piv_cur) {
     constexpr int S = P / QL, T = P % QL;
     if constexpr (OP == 0) {
-        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                     : "=v"(ch.piv) : "v"(q.r[S][P]), "n"(T));
+        // DPP read of a[P][P], written by the first FMA of column P of the running step: two
+        // wait states are needed in between.  QS - 1 - S further FMAs of that column follow
+        // the write, and the compiler puts one s_nop 0 in front of this statement (see
+        // above); the rest is supplied here.  tools/check_dpp_hazard.py checks the result.
+        constexpr int have = (QS - 1 - S) + 1;
+        if constexpr (P == 0 || have < 2)
+            asm volatile("s_nop %3\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                         : "=v"(ch.piv) : "v"(q.r[S][P]), "n"(T), "n"(P == 0 ? 1 : 1 - have));
+        else
+            asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                         : "=v"(ch.piv) : "v"(q.r[S][P]), "n"(T));
     } else if constexpr (OP == 1) {
-        asm volatile("v_rcp_f64 %0, %1" : "=v"(ch.r) : "v"(ch.piv));
-    } else if constexpr (OP == 2 || OP == 4) {
-        // (a transcendental result needs a wait state before a VALU read)
-        asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(ch.e) : "v"(ch.piv), "v"(ch.r));
-    } else if constexpr (OP == 3 || OP == 5) {
-        asm volatile("v_fma_f64 %0, %1, %0, %0" : "+v"(ch.r) : "v"(ch.e));
+        if constexpr (P > 0) {
+            da.det *= piv_cur;
+            da.sign |= __double2hiint(piv_cur);
+        }
+    } else if constexpr (OP == 2) {
+        ch.r = __builtin_amdgcn_rcp(ch.piv);
+    } else if constexpr (OP < 3 + NEWTON_OPS) {
+        if constexpr (OP == 3) ch.e = fma(-ch.piv, ch.r, 1.0);
+        else if constexpr (OP == 4) ch.e = fma(ch.e, ch.e, ch.e);
+        else ch.r = fma(ch.r, ch.e, ch.r);
     } else {
-        constexpr int s = OP - 6;
-        if constexpr (s >= S) asm volatile("v_mul_f64 %0, -%1, %2" : "=v"(ln[s]) : "v"(q.r[s][P]), "v"(ch.r));
+        constexpr int s = OP - 3 - NEWTON_OPS;
+        if constexpr (s >= S) ln[s] = -q.r[s][P] * ch.r;
         else ln[s] = 0.0;
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int P, int OP>
-__device__ __forceinline__ void chain_rest(QuadRows& q, PivotChain& ch, double (&ln)[QS]) {
+__device__ __forceinline__ void chain_rest(QuadRows& q, PivotChain& ch, double (&ln)[QS], DetAcc& da, double piv_cur) {
     if constexpr (OP < CHAIN_OPS) {
-        chain_op<P, OP>(q, ch, ln);
-        chain_rest<P, OP + 1>(q, ch, ln);
+        chain_op<P, OP>(q, ch, ln, da, piv_cur);
+        chain_rest<P, OP + 1>(q, ch, ln, da, piv_cur);
     }
 }
 
 // column J of step K (see TriCol), followed by the chain operations that are due
 template <int K, int J, int OP>
 struct TriColAhead {
-    static __device__ __forceinline__ void run(QuadRows& q, const double (&l)[QS], PivotChain& ch, double (&ln)[QS]) {
+    static __device__ __forceinline__ void run(QuadRows& q, const double (&l)[QS], PivotChain& ch, double (&ln)[QS],
+                                               DetAcc& da, double piv_k) {
         if constexpr (J < D) {
             constexpr int SJ = J / QL, TJ = J % QL;
             fmac_bcast16<TJ, false>(q.r[SJ][J], q.r[SJ][K], l[SJ]);
@@ -142,10 +171,14 @@ struct TriColAhead {
             constexpr int avail = D - 1 - first;               // columns behind it
             constexpr int gap = avail >= 2 * CHAIN_OPS ? 2 : 1;
             constexpr bool emit = OP < CHAIN_OPS && ((J - first) % gap == 0);
-            if constexpr (emit) chain_op<K + 1, OP>(q, ch, ln);
-            TriColAhead<K, J + 1, emit ? OP + 1 : OP>::run(q, l, ch, ln);
+            if constexpr (emit) {
+                __builtin_amdgcn_sched_barrier(0);
+                chain_op<K + 1, OP>(q, ch, ln, da, piv_k);
+            }
+            TriColAhead<K, J + 1, emit ? OP + 1 : OP>::run(q, l, ch, ln, da, piv_k);
         } else {
-            chain_rest<K + 1, OP>(q, ch, ln);                  // what did not fit between the columns
+            __builtin_amdgcn_sched_barrier(0);
+            chain_rest<K + 1, OP>(q, ch, ln, da, piv_k);       // what did not fit between the columns
         }
     }
 };
@@ -153,14 +186,15 @@ struct TriColAhead {
 template <int K>
 struct TriStepAhead {
     // l: multipliers of step K (ready); piv_k: its pivot (for the determinant)
-    static __device__ __forceinline__ void run(QuadRows& q, double& det, double& pmin, const double (&l)[QS], double piv_k) {
-        asm("v_min_f64 %0, %1, %2" : "=v"(pmin) : "v"(pmin), "v"(piv_k));    // (fmin() adds a canonicalisation)
-        det *= piv_k;
+    static __device__ __forceinline__ void run(QuadRows& q, DetAcc& da, const double (&l)[QS], double piv_k) {
         if constexpr (K + 1 < D) {
             PivotChain ch;
             double ln[QS];
-            TriColAhead<K, K + 1, 0>::run(q, l, ch, ln);
-            TriStepAhead<K + 1>::run(q, det, pmin, ln, ch.piv);
+            TriColAhead<K, K + 1, 0>::run(q, l, ch, ln, da, piv_k);
+            TriStepAhead<K + 1>::run(q, da, ln, ch.piv);
+        } else {
+            da.det *= piv_k;
+            da.sign |= __double2hiint(piv_k);
         }
     }
 };
@@ -168,14 +202,16 @@ struct TriStepAhead {
 // det (per DPP row) of four symmetric matrices given by their lower triangles.
 // false: some pivot was not a positive finite number (or the product left the range).
 __device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out) {
-    double det = 1.0;
-    double pmin = __builtin_huge_val();
+    DetAcc da;
+    da.det = 1.0;
+    da.sign = 0;
     PivotChain ch;
     double l0[QS];
-    chain_rest<0, 0>(q, ch, l0);                               // the first pivot's chain: nothing to hide it under
-    TriStepAhead<0>::run(q, det, pmin, l0, ch.piv);
-    det_out = det;
-    return (pmin > 0.0) && (det == det) && (det < __builtin_huge_val());
+    __builtin_amdgcn_sched_barrier(0);
+    chain_rest<0, 0>(q, ch, l0, da, 1.0);                      // the first pivot's chain: nothing to hide it under
+    TriStepAhead<0>::run(q, da, l0, ch.piv);
+    det_out = da.det;
+    return (da.sign >= 0) && (da.det == da.det) && (da.det < __builtin_huge_val());
 }
 
 // q[s][J] += c[s] * v_J for the lower-triangle columns (v distributed like the rows)

@@ -42,15 +42,24 @@ def main():
         print('k_gw %.1f ms; turns %d scans %d; cycles/scan %.0f' % (tm['gw'][-1], v[5], v[4], tot / max(v[4], 1)))
         for name, x in zip(('prefix build', 'scan set-up', 'log-det jobs', 'finish+argmax'), v[:4]):
             print('  %-14s %5.1f %%   %8.0f cycles/scan' % (name, 100.0 * x / tot, x / max(v[4], 1)))
+        pp = (C.c_ulonglong * 4)()
+        lib.spkd_debug_pass_prof(pp)
+        print('  per wave pass: %.0f cycles, of which %.0f waiting for its record loads' % (pp[1] / max(pp[2], 1), pp[0] / max(pp[2], 1)))
+        print('  items %d = %.1f per scan; wave passes %d = %.2f per scan' % (v[7], v[7] / max(v[4], 1), v[6], v[6] / max(v[4], 1)))
         for name, x in zip(('sweep: accumulate', 'sweep: dumps', 'sweep: staging'), v[8:11]):
             print('    %-18s %8.0f cycles/scan' % (name, x / max(v[4], 1)))
     # the merge loop: how many row caches a merge invalidates (each is a full row rescan)
     segs = pipeline.change_detect_batch(ctx, frames.data_ptr(), files_n * T, files, 125.0, pipeline.DIA2_CD)
     a4 = (C.c_ulonglong * 8)()
     lib.spkd_debug_ahc_prof(a4)
+    pp = (C.c_ulonglong * 4)()
+    lib.spkd_debug_pass_prof(pp)           # (zeroes the counters)
     tm = {}
     pipeline.cluster_batch(ctx, frames.data_ptr(), files_n * T, files, segs, 125.0, pipeline.DIA2_CL, tm)
     lib.spkd_debug_ahc_prof(a4)
+    lib.spkd_debug_pass_prof(pp)
+    print('k_matrix + k_ahc: per wave pass %.0f cycles, of which %.0f waiting for its record loads (%d passes)' % (
+        pp[1] / max(pp[2], 1), pp[0] / max(pp[2], 1), pp[2]))
     print('k_ahc %.1f ms; merges %d; rows rescanned %d = %.1f per merge' % (
         tm['ahc'][-1], a4[1], a4[0], a4[0] / max(a4[1], 1)))
     tot = float(sum(a4[2:7]))
