@@ -62,9 +62,12 @@ def parse():
                     help='distinct synthetic sessions (0 = every file its own; fewer are tiled)')
     ap.add_argument('--seconds', type=float, default=3600.0)
     ap.add_argument('--speakers', type=int, default=4)
-    ap.add_argument('--streams', type=int, default=1,
-                    help='host threads, each with its own library context (a stream of its own) and an '
-                         'equal share of the files: the host work of one share overlaps the kernels of another')
+    ap.add_argument('--in-flight', type=int, default=1,
+                    help='batches in flight per GPU: that many host threads, each with a library context on a '
+                         'stream of its own, take the steps in turn; kernels of different batches then share '
+                         'the GPU (tails overlap with the next launch) and their HIP-event durations are no '
+                         'longer those of a kernel alone.  Default 1: strictly one step at a time; the '
+                         'two-in-flight rate is reported beside it as "two_batches_in_flight"')
     ap.add_argument('--two-pass', action='store_true',
                     help='read the frames once per stage (k_chunk_stats) instead of the fused single read')
     ap.add_argument('--cpu-sample-seconds', type=float, default=900.0)
@@ -209,56 +212,86 @@ def main():
     del sessions
     total = args.files * T
     torch.cuda.synchronize()
-    # the library launches on torch's current stream (handle 0 = the default stream)
-    ctx = hipabi.Context(local, torch.cuda.current_stream().cuda_stream)
+    # The library launches on the stream it is given.  One context per batch in flight; with
+    # more than one, each sits on a (non-blocking) torch stream of its own and is driven by
+    # its own host thread (ctypes and numpy release the GIL).
+    depth = max(1, args.in_flight)
+    if depth == 1:
+        lanes = [hipabi.Context(local, torch.cuda.current_stream().cuda_stream)]
+        lane_streams = []
+    else:
+        lane_streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        lanes = [hipabi.Context(local, s.cuda_stream) for s in lane_streams]
+    ctx = lanes[0]
     ptr = frames.data_ptr()
     fused = not args.two_pass
     cl = dict(pipeline.DIA2_CL, path=args.ahc_path)
 
-    # optional: several host threads, each driving its share of the files through its own
-    # context (ctypes and numpy release the GIL; the library is thread-safe per context)
-    n_streams = max(1, min(args.streams, args.files))
-    shares = [list(range(k, args.files, n_streams)) for k in range(n_streams)]
-    ctxs = [ctx] + [hipabi.Context(local) for _ in range(n_streams - 1)]
+    def compute(lane, tm=None, lanes_=None):
+        """One pass of the hot path over the batch -> rows per local file."""
+        return pipeline.diarize_batch((lanes_ or lanes)[lane], ptr, total, files, cl=cl, timings=tm, fused=fused)
 
-    def run_share(k, tm):
-        sub = [files[i] for i in shares[k]]
-        return pipeline.diarize_batch(ctxs[k], ptr, total, sub, cl=cl, timings=tm, fused=fused)
-
-    def step(tm=None):
-        if n_streams == 1:
-            rows = pipeline.diarize_batch(ctx, ptr, total, files, cl=cl, timings=tm, fused=fused)
-        else:
-            import threading
-            parts = [None] * n_streams
-            tms = [({} if tm is not None else None) for _ in range(n_streams)]
-
-            def work(k):
-                parts[k] = run_share(k, tms[k])
-
-            th = [threading.Thread(target=work, args=(k,)) for k in range(1, n_streams)]
-            for t_ in th:
-                t_.start()
-            work(0)
-            for t_ in th:
-                t_.join()
-            rows = [None] * args.files
-            for k in range(n_streams):
-                for i, r in zip(shares[k], parts[k]):
-                    rows[i] = r
-            if tm is not None:                     # kernel times: sums over the shares (they overlap in time)
-                for k in range(n_streams):
-                    for key, v in tms[k].items():
-                        if isinstance(v, list):
-                            tm.setdefault(key, [])
-                            if len(tm[key]) < len(tms[0].get(key, v)) or k == 0:
-                                tm[key] = [a + b for a, b in zip(tm[key], v)] if (k > 0 and len(tm[key]) == len(v)) else list(v)
-                        else:
-                            tm[key] = tm.get(key, 0) + v if k > 0 else v
+    def deliver(rows):
         if world == 1:
             return {i: r for i, r in enumerate(rows)}
         # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)
         return distributed.gather_rows([(rank + world * i, r) for i, r in enumerate(rows)], dist)
+
+    def step(tm=None):
+        return deliver(compute(0, tm))
+
+    def run_steps(k_steps, tm, lanes_=None):
+        """k_steps passes, at most one per lane in flight; the gathers run on this thread in
+        step order (collectives must be issued in the same order on every rank)."""
+        depth = len(lanes_ or lanes)
+        if depth == 1 or k_steps <= 1:
+            out_ = None
+            for _ in range(k_steps):
+                out_ = step(tm)
+            return out_
+        import threading
+        results = [None] * k_steps
+        done = [threading.Event() for _ in range(k_steps)]
+        tms = [{} for _ in range(depth)]
+        nxt = [0]
+        lock = threading.Lock()
+        failure = []
+
+        def worker(lane):
+            while True:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= k_steps:
+                    return
+                try:
+                    results[k] = compute(lane, tms[lane], lanes_)
+                except BaseException as e:           # surfaces on the main thread
+                    failure.append(e)
+                finally:
+                    done[k].set()
+
+        th = [threading.Thread(target=worker, args=(lane,)) for lane in range(depth)]
+        for t_ in th:
+            t_.start()
+        out_ = None
+        for k in range(k_steps):
+            done[k].wait()
+            if failure:
+                break
+            out_ = deliver(results[k])
+            results[k] = None
+        for t_ in th:
+            t_.join()
+        if failure:
+            raise failure[0]
+        for lane_tm in tms:                          # per-launch kernel times of all lanes
+            for key, v in lane_tm.items():
+                if isinstance(v, list):
+                    tm.setdefault(key, []).extend(v)
+                else:
+                    tm[key] = v
+        return out_
 
     def barrier():
         torch.cuda.synchronize()
@@ -288,11 +321,13 @@ def main():
     digest0 = rows_digest(out) if out is not None else None
     for _ in range(max(0, args.warmup - 1)):
         out = step()
+    if depth > 1:                                    # every lane's scratch is sized before the clock starts
+        for lane in range(1, depth):
+            compute(lane)
     timings = {}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(timings)
+    out = run_steps(args.steps, timings)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -364,7 +399,7 @@ def main():
                        'segments_per_step': n_sets,
                        'segments_recomputed_from_frames': timings.get('stats_recomputed', n_sets),
                        'parallelism': 'file-sharded x%d, no data-path collective' % world,
-                       'host_threads_per_gpu': n_streams},
+                       'batches_in_flight_per_gpu': depth},
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_source': traffic_note},
@@ -374,6 +409,28 @@ def main():
             'device_ms_per_step': round(sum(v[0] for v in kernels.values()) + avg('cluster_prep') + avg('reduce_sets'), 3),
             'verified': verified,
         }
+        if world == 1 and not args.no_extras and depth == 1:
+            # the same job with two batches in flight: a second context on a stream of its own, a
+            # host thread per context; the kernels of consecutive batches share the GPU (the tail of
+            # one launch runs beside the head of the next), so this is a throughput figure
+            # only -- per-kernel durations under it are not those of a kernel alone
+            side = torch.cuda.Stream(device=dev)     # (non-blocking: independent of the default stream)
+            two = [ctx, hipabi.Context(local, side.cuda_stream)]
+            try:
+                compute(1, None, two)                # sizes the second context's scratch
+                torch.cuda.synchronize()
+                k2 = max(4, args.steps)
+                t2 = time.perf_counter()
+                out2 = run_steps(k2, {}, two)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t2
+            finally:
+                two[1].close()
+            if rows_digest(out2) != digest0:
+                raise SystemExit('bench.py: the two-in-flight run produced different rows')
+            res['two_batches_in_flight'] = {'value': args.files * (args.seconds / 3600.0) * k2 / dt2,
+                                            'unit': 'hours-audio/s', 'steps': k2,
+                                            'ms_per_step': round(1e3 * dt2 / k2, 2)}
         if world == 1 and not args.no_extras:
             res['hbm_copy_GBps'] = round(copy_rate(torch, dev), 1)
             res['other_configs'] = other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, local)
