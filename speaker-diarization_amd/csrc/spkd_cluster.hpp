@@ -984,40 +984,65 @@ __device__ __forceinline__ void ahc_select_body(
     int32_t* ids = ids_all + off;
     AhcState* S = state + p;
     const long long INF_IDX = 0x7fffffffffffffffLL;
-    int n_merges = 0;
-    if (it > 0) {
-        n_merges = S->n_merges;
-        // ---- 0. the merged cluster's own row: cache + the running statistics of
-        // variant 1 over the distances just evaluated
-        const long long psa = S->sa;
-        const double* row = mat + mat_off[p] + psa * N;
-        double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
-        int mc = NO_COL, nc = NO_COL;
-#pragma unroll 4
-        for (long long c = tid; c < N; c += AHC_TPB) {
-            const int a = al[c];
-            const double d = row[c];
-            if (!a) continue;
-            if (variant == 1 && c != psa && stat_valid(d)) {
+    const int n_merges = it > 0 ? S->n_merges : 0;
+    const long long psa = it > 0 ? S->sa : -1;       // the row the round just rewrote (none before the first merge)
+    const long long m = N - n_merges;
+    // ---- 0 + 1 in ONE pass over x = 0 .. N - 1 (one memory round trip): x as a COLUMN of
+    // row psa -- that row's fresh cache and, variant 1, the running statistics over the
+    // distances just evaluated -- and x as a ROW of the arg-min over the row caches (k_ahc
+    // step 1; row psa enters with its fresh values below)
+    const double* rowp = mat + mat_off[p] + (psa >= 0 ? psa : 0) * N;
+    double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
+    int mc = NO_COL, nc = NO_COL;
+    ArgMin mine;
+    mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+#pragma unroll 2
+    for (long long x = tid; x < N; x += AHC_TPB) {
+        const int a = al[x];
+        const double d = rowp[x];
+        const double v = rmin[x];
+        const int c = rarg[x], rn = rnan[x];
+        if (!a) continue;
+        if (psa >= 0) {
+            if (variant == 1 && x != psa && stat_valid(d)) {
                 wmax = (wmax != wmax || d > wmax) ? d : wmax;
                 wmin = (wmin != wmin || d < wmin) ? d : wmin;
             }
-            if (d != d) { if ((int)c < nc) nc = (int)c; continue; }
-            if (d < mv || (d == mv && (int)c < mc)) { mv = d; mc = (int)c; }
+            if (d != d) { if ((int)x < nc) nc = (int)x; }
+            else if (d < mv || (d == mv && (int)x < mc)) { mv = d; mc = (int)x; }
         }
+        if (x != psa) {
+            if (rn != NO_COL) { const long long l = x * N + rn; if (l < mine.nan_idx) mine.nan_idx = l; }
+            if (c != NO_COL) {
+                const long long l = x * N + c;
+                if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+            }
+        }
+    }
 #pragma unroll
-        for (int s = 1; s < WAVE; s <<= 1) {
-            const double v2 = __shfl_xor(mv, s);
-            const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
-            if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
-            nc = n2 < nc ? n2 : nc;
-            const double x = __shfl_xor(wmax, s), y = __shfl_xor(wmin, s);
-            if (x == x && (wmax != wmax || x > wmax)) wmax = x;
-            if (y == y && (wmin != wmin || y < wmin)) wmin = y;
-        }
-        if (lane == 0) { rred[wave].mv = mv; rred[wave].mc = mc; rred[wave].nc = nc; rred[wave].wmax = wmax; rred[wave].wmin = wmin; }
-        __syncthreads();
-        if (tid == 0) {
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double v2 = __shfl_xor(mv, s);
+        const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+        if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+        nc = n2 < nc ? n2 : nc;
+        const double x = __shfl_xor(wmax, s), y = __shfl_xor(wmin, s);
+        if (x == x && (wmax != wmax || x > wmax)) wmax = x;
+        if (y == y && (wmin != wmin || y < wmin)) wmin = y;
+        ArgMin o;
+        o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
+        argmin_merge(mine, o);
+    }
+    if (lane == 0) {
+        rred[wave].mv = mv; rred[wave].mc = mc; rred[wave].nc = nc; rred[wave].wmax = wmax; rred[wave].wmin = wmin;
+        red[wave] = mine;
+    }
+    if (tid < 2) s_cnt[tid] = 0;
+    if (tid == 0) s_nids = 1;
+    __syncthreads();
+    if (tid == 0) {
+        ArgMin b = red[0];
+        for (int w = 1; w < AHC_WAVES; ++w) argmin_merge(b, red[w]);
+        if (psa >= 0) {
             for (int w = 1; w < AHC_WAVES; ++w) {
                 const RowRed o = rred[w];
                 if (o.mv < mv || (o.mv == mv && o.mc < mc)) { mv = o.mv; mc = o.mc; }
@@ -1030,38 +1055,12 @@ __device__ __forceinline__ void ahc_select_body(
                 if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
                 if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
             }
+            ArgMin own;                              // row psa as a candidate of the arg-min
+            own.v = mc != NO_COL ? mv : __builtin_huge_val();
+            own.idx = mc != NO_COL ? psa * N + mc : INF_IDX;
+            own.nan_idx = nc != NO_COL ? psa * N + nc : INF_IDX;
+            argmin_merge(b, own);
         }
-        __syncthreads();
-    }
-    const long long m = N - n_merges;
-    // ---- 1. arg-min over the row caches (k_ahc step 1)
-    ArgMin mine;
-    mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
-#pragma unroll 4
-    for (long long r = tid; r < N; r += AHC_TPB) {
-        const int a = al[r];
-        const double v = rmin[r];
-        const int c = rarg[r], nc = rnan[r];
-        if (!a) continue;
-        if (nc != NO_COL) { const long long l = r * N + nc; if (l < mine.nan_idx) mine.nan_idx = l; }
-        if (c != NO_COL) {
-            const long long l = r * N + c;
-            if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
-        }
-    }
-#pragma unroll
-    for (int s = 1; s < WAVE; s <<= 1) {
-        ArgMin o;
-        o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
-        argmin_merge(mine, o);
-    }
-    if (lane == 0) red[wave] = mine;
-    if (tid < 2) s_cnt[tid] = 0;
-    if (tid == 0) s_nids = 1;
-    __syncthreads();
-    if (tid == 0) {
-        ArgMin b = red[0];
-        for (int w = 1; w < AHC_WAVES; ++w) argmin_merge(b, red[w]);
         best = b;
     }
     __syncthreads();
@@ -1165,6 +1164,8 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
         int* err) {
     __shared__ double ldsA[QREC];
     __shared__ double s_ldx[4 * AHC_WAVES];
+    __shared__ double s_dfin[4 * AHC_WAVES];
+    __shared__ int s_rescan[4 * AHC_WAVES];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
@@ -1207,33 +1208,44 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_round(
     }
     const double ldA = kind == SPKD_KL2 ? 0.0 : log(s_ldx[0]);
     if (kind != SPKD_KL2 && blockIdx.x == 0 && tid == 0) ldp[sa] = ldA;      // the merged cluster's cached term
-    // ---- finish this workgroup's distances, row / column sa, the partner rows' caches
-    // (a wave per row: a row whose cached minimum was invalidated is rescanned at once)
-    for (int j = 1 + wave; j <= mine; j += AHC_WAVES) {
-        const long long r = ids[first + j - 1];
-        const double d = ahc_finish(kind, lambdac, ex, aux, ldp, kind == SPKD_KL2 ? 0.0 : log(s_ldx[j]), off, sa, r, nA, ldA);
-        const int ra = rarg[r], rn = rnan[r];
-        const double rm = rmin[r];
-        double mv;
-        int mc, nc;
-        if (lane == 0) Dm[sa * N + r] = d;
-        if (variant == 1) {
-            if (lane == 0) Dm[r * N + sa] = d;
-            const bool nan_hit = (rn == sa || rn == sb);
-            if (ra == sa || ra == sb || nan_hit) {
-                if (!nan_hit && d < rm) {            // still (or now) the strict row minimum
-                    if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
-                } else {
-                    ahc_scan_row(Dm + r * N, N, al, false, sa, d, lane, mv, mc, nc);
-                    if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
+    // ---- finish this workgroup's distances, row / column sa, the partner rows' caches: one
+    // THREAD per partner (their loads travel together: one memory round trip for the
+    // chunk, where a wave per row made one per row); the rows whose cached minimum was
+    // invalidated are then rescanned, a wave per row
+    {
+        const int j = tid;                           // partner j = 1 .. mine (<= 31: the first wave)
+        bool rescan = false;
+        double d = 0.0;
+        if (j >= 1 && j <= mine) {
+            const long long r = ids[first + j - 1];
+            d = ahc_finish(kind, lambdac, ex, aux, ldp, kind == SPKD_KL2 ? 0.0 : log(s_ldx[j]), off, sa, r, nA, ldA);
+            const int ra = rarg[r], rn = rnan[r];
+            const double rm = rmin[r];
+            Dm[sa * N + r] = d;
+            if (variant == 1) {
+                Dm[r * N + sa] = d;
+                const bool nan_hit = (rn == sa || rn == sb);
+                if (ra == sa || ra == sb || nan_hit) {
+                    if (!nan_hit && d < rm) { rmin[r] = d; rarg[r] = (int)sa; }    // still (or now) the strict row minimum
+                    else rescan = true;
+                } else if (d != d) {
+                    if ((int)sa < rn) rnan[r] = (int)sa;
+                } else if (d < rm || (d == rm && (int)sa < ra)) {
+                    rmin[r] = d; rarg[r] = (int)sa;
                 }
-            } else if (d != d) {
-                if (lane == 0 && (int)sa < rn) rnan[r] = (int)sa;
-            } else if (d < rm || (d == rm && (int)sa < ra)) {
-                if (lane == 0) { rmin[r] = d; rarg[r] = (int)sa; }
+            } else if (ra == sb || rn == sb) {       // column sa keeps its stale value (A-9)
+                rescan = true;
             }
-        } else if (ra == sb || rn == sb) {           // column sa keeps its stale value (A-9)
-            ahc_scan_row(Dm + r * N, N, al, false, -1, 0.0, lane, mv, mc, nc);
+        }
+        if (tid < 4 * AHC_WAVES) { s_rescan[tid] = rescan ? 1 : 0; s_dfin[tid] = d; }
+        __syncthreads();
+        for (int jj = 1 + wave; jj <= mine; jj += AHC_WAVES) {
+            if (!s_rescan[jj]) continue;             // (wave-uniform)
+            const long long r = ids[first + jj - 1];
+            double mv;
+            int mc, nc;
+            // variant 1: the row's own fresh cell (column sa) is taken from the value just computed
+            ahc_scan_row(Dm + r * N, N, al, false, variant == 1 ? sa : -1, s_dfin[jj], lane, mv, mc, nc);
             if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; }
         }
     }
