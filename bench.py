@@ -400,8 +400,12 @@ def main():
                        'segments_recomputed_from_frames': timings.get('stats_recomputed', n_sets),
                        'parallelism': 'file-sharded x%d, no data-path collective' % world,
                        'batches_in_flight_per_gpu': depth},
+            # achieved / frac: ALGORITHMIC bytes per launch over the measured launch
+            # duration; traffic: counted HBM bytes per launch (PMC), traffic_GBps the same over
+            # the same duration -- what the memory system actually carries for this kernel
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'traffic_GBps': round(traffic / 1e9 / (dms / 1e3), 1) if traffic and dms > 0 else None,
                          'traffic_source': traffic_note},
             'kernels': per_kernel,
             'wall_ms': {k[5:]: round(float(np.mean(v)), 2) for k, v in timings.items() if k.startswith('wall_')},
