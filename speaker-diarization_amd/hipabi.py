@@ -61,6 +61,32 @@ class SpkdError(RuntimeError):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch wheels bundle their own
+    (torch/lib/libamdhip64.so): if this library is loaded first it pulls in the system
+    runtime, and a later `import torch` finds that foreign runtime under its soname and
+    reports "No HIP GPUs are available".  So when a PyTorch installation is present but not
+    imported yet, its runtime is loaded first (the wheel's file only: torch itself is not
+    imported), and libspkd_hip.so binds to it -- the same situation as after `import
+    torch`.  SPKD_SYSTEM_HIP=1 keeps the system runtime."""
+    import sys
+    if 'torch' in sys.modules or os.environ.get('SPKD_SYSTEM_HIP'):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        where = list(spec.submodule_search_locations)[0] if spec and spec.submodule_search_locations else None
+    except (ImportError, ValueError, AttributeError):
+        where = None
+    if where:
+        rt = os.path.join(where, 'lib', 'libamdhip64.so')
+        if os.path.exists(rt):
+            try:
+                C.CDLL(rt, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load_library(path=None):
     """Loads libspkd_hip.so; raises (never falls back) when it is missing."""
     global _lib
@@ -70,6 +96,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise ImportError('HIP extension %s is not built: run `python -c "import __graft_entry__ as g; '
                           'g.build()"` (or make -C speaker-diarization_amd/csrc)' % p)
+    _one_hip_runtime()
     lib = C.CDLL(p)
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     P = C.POINTER

@@ -3,6 +3,8 @@ every symbol include/spkd.h declares (no compute calls without a GPU)."""
 import os
 import re
 
+import pytest
+
 from helpers import ROOT
 from conftest import pkg
 
@@ -83,3 +85,19 @@ def test_product_has_no_cpu_path():
         if fn.endswith('.py'):
             src = open(os.path.join(base, fn)).read()
             assert 'oracle' not in src.replace('the CPU oracle', '').replace('CPU oracle', ''), fn
+
+
+@pytest.mark.gpu
+def test_library_before_torch_in_one_process():
+    """PyTorch wheels bundle a HIP runtime of their own; a process that created a library
+    context before importing torch used to end up with two runtimes and torch reported "No
+    HIP GPUs are available".  hipabi loads the wheel's runtime first when a torch
+    installation is present: both orders work (a fresh process: this one imported torch in
+    conftest.py)."""
+    pytest.importorskip('torch')
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'order_child.py')
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'then torch: True' in r.stdout and 'library again: merges' in r.stdout
