@@ -65,6 +65,37 @@ def test_one_hour_matches_c_oracle(tmp_path, eng, nspk, seed):
         nspk, h[0].count('\n'), len(mh), worst))
 
 
+def test_twenty_minutes_glr_matches_c_oracle(tmp_path, eng):
+    """The GLR branch of both stages at length (the goldens hold it at 150 s): growing-window
+    GLR change detection (three matrices per candidate), then v2 clustering on GLR."""
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    cli = pkg('cli')
+    feats, vad, _ = synth.make_session(60606, 1200, 5)
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    synth.write_fea(os.path.join(tmp, 'fea', 'glr.fea'), feats)
+    with open(os.path.join(tmp, 'vad.recipe'), 'w') as f:
+        f.write(synth.vad_recipe_text('glr.wav', vad))
+    res = {}
+    for tag, engine in (('hip', eng), ('orc', COracleEngine())):
+        spkc = os.path.join(tmp, tag + '.spkc.recipe')
+        final = os.path.join(tmp, tag + '.out.recipe')
+        o1, o2 = io.StringIO(), io.StringIO()
+        cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), os.path.join(tmp, 'fea') + '/', '-o', spkc,
+                                   '-m', 'gw', '-d', 'GLR', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-t', '900'],
+                                  engine=engine, stdout=o1)
+        cli.main_clustering([spkc, os.path.join(tmp, 'fea') + '/', '-o', final, '-m', 'hi', '-d', 'GLR',
+                             '-t', '1500'], variant=2, engine=engine, stdout=o2)
+        res[tag] = (open(spkc).read(), open(final).read(), o2.getvalue())
+    assert res['hip'][0] == res['orc'][0]
+    assert res['hip'][1] == res['orc'][1]
+    assert res['hip'][0].count('\n') > 100
+    mh, mo = _merge_lines(res['hip'][2]), _merge_lines(res['orc'][2])
+    assert len(mh) > 50 and [(a, b) for a, b, _ in mh] == [(a, b) for a, b, _ in mo]
+    assert max(abs(x[2] - y[2]) / max(1.0, abs(y[2])) for x, y in zip(mh, mo)) < 1e-9
+
+
 def test_statistics_are_additive(eng):
     synth = pkg('synth')
     feats, _, _ = synth.make_session(99, 300, 3)
