@@ -96,6 +96,52 @@ def test_twenty_minutes_glr_matches_c_oracle(tmp_path, eng):
     assert max(abs(x[2] - y[2]) / max(1.0, abs(y[2])) for x, y in zip(mh, mo)) < 1e-9
 
 
+def test_random_parameters_match_c_oracle(tmp_path, eng):
+    """The growing-window state machine over parameter combinations the goldens do not hold
+    (window, step, growth, penalty / threshold, every distance), short sessions with ragged
+    turns, against the C oracle (itself pinned by the reference's goldens): the change
+    recipe byte for byte, then the clustering recipe of either script version."""
+    import random
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    cli = pkg('cli')
+    rnd = random.Random(20261004)
+    orc = COracleEngine()
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    for trial in range(14):
+        secs = rnd.choice([45, 90, 140])
+        nspk = rnd.choice([2, 3, 4])
+        kw = rnd.choice([{}, dict(min_turn=1.5, max_turn=4.0), dict(min_turn=6.0, max_turn=25.0)])
+        feats, vad, _ = synth.make_session(9000 + trial, secs, nspk, **kw)
+        name = 'r%d' % trial
+        synth.write_fea(os.path.join(tmp, 'fea', name + '.fea'), feats)
+        vr = os.path.join(tmp, name + '.vad.recipe')
+        with open(vr, 'w') as f:
+            f.write(synth.vad_recipe_text(name + '.wav', vad))
+        kind = rnd.choice(['BIC', 'BIC', 'GLR', 'KL2'])
+        w = rnd.choice(['0.5', '1.0', '1.5', '2.0'])
+        st = rnd.choice(['0.3', '1.0', '2.5', '3.0'])
+        dws = rnd.choice(['0.05', '0.1', '0.3'])
+        cd = ['-m', 'gw', '-d', kind, '-w', w, '-st', st, '-dws', dws]
+        cd += {'BIC': ['-l', rnd.choice(['0.8', '1.0', '1.4'])], 'GLR': ['-t', rnd.choice(['700', '900', '1200'])],
+               'KL2': ['-t', rnd.choice(['40', '60'])]}[kind]
+        ckind = rnd.choice(['BIC', 'GLR'])
+        variant = rnd.choice([1, 2])
+        cl = ['-m', 'hi', '-d', ckind] + (['-l', rnd.choice(['1.0', '1.3'])] if ckind == 'BIC' else ['-t', '1500'])
+        out = {}
+        for tag, engine in (('hip', eng), ('orc', orc)):
+            spkc = os.path.join(tmp, '%s.%s.spkc' % (name, tag))
+            final = os.path.join(tmp, '%s.%s.out' % (name, tag))
+            cli.main_change_detection([vr, os.path.join(tmp, 'fea') + '/', '-o', spkc] + cd, engine=engine,
+                                      stdout=io.StringIO())
+            cli.main_clustering([spkc, os.path.join(tmp, 'fea') + '/', '-o', final] + cl, variant=variant,
+                                engine=engine, stdout=io.StringIO())
+            out[tag] = (open(spkc).read(), open(final).read())
+        assert out['hip'][0] == out['orc'][0], (trial, cd)
+        assert out['hip'][1] == out['orc'][1], (trial, cd, cl, variant)
+
+
 def test_statistics_are_additive(eng):
     synth = pkg('synth')
     feats, _, _ = synth.make_session(99, 300, 3)
