@@ -93,15 +93,7 @@ __global__ __launch_bounds__(512) void k_pairs(const double* __restrict__ qr, in
             double det; tri_det_nopivot(q, det);
             acc += log(det);
         } else {
-            const double* recs[4];
-            bool selfs[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                int c = base + mi; c = c < WINDOW ? c : WINDOW - 1;
-                recs[mi] = qr + (size_t)((a + 1 + c) % n_rec) * QREC;
-                selfs[mi] = false;
-            }
-            const double ldx = log(quad_pair_det<false>(SPKD_BIC, ldsA, nA, A, C, pk + (size_t)rc * REC, false, L, recs, selfs, err));
+            const double ldx = log(quad_pair_det<false>(SPKD_BIC, ldsA, nA, A, C, pk + (size_t)rc * REC, false, L, err));
             const double d = finish_distance(SPKD_BIC, 1.3, nA, ldA, qr_count(C), ld[rc], ldx);
             if (valid && L.t == 0) out[(size_t)blockIdx.x * WINDOW + w] = d;
             acc += d;
