@@ -59,14 +59,26 @@ __device__ __forceinline__ void head_cols(double (&b0)[QL], double l) {
 }
 
 // slot 0 alone: steps 0..12 on the 13 x 13 block (row t of the DPP row in lane t)
+// this lane's number, computed where it is wanted (a value kept for the whole pass is spilled:
+// the registers are full during steps 0..38 of slots 1 and 2)
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 template <int K>
-__device__ __forceinline__ void head_step(double (&b0)[QL], DetAcc& da, double* m0_lane, double* rk_row, bool first) {
+__device__ __forceinline__ void head_step(double (&b0)[QL], DetAcc& da, double* m0_wave, double* rk_wave) {
     if constexpr (K < QL) {
         double piv;
         asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(piv) : "v"(b0[K]), "n"(K));
         da.det *= piv;
         da.sign |= __double2hiint(piv);
-        __builtin_amdgcn_sched_barrier(0);                   // (keeps the product here: deferred, the pivots are spilled)
+        asm volatile("" : "+v"(da.det), "+v"(da.sign));      // (the product is taken here: deferred, the pivots are spilled)
+        const int lane = fresh_lane();
+        double* m0_lane = m0_wave + (lane >> 4) * (QL * 16) + (lane & 15);
+        double* rk_row = rk_wave + (lane >> 4) * 16;
+        const bool first = (lane & 15) == 0;
         double r = __builtin_amdgcn_rcp(piv);
         double e = fma(-piv, r, 1.0);
         e = fma(e, e, e);
@@ -77,7 +89,7 @@ __device__ __forceinline__ void head_step(double (&b0)[QL], DetAcc& da, double* 
         __builtin_amdgcn_sched_barrier(0);
         head_cols<K, K + 1>(b0, l);
         __builtin_amdgcn_sched_barrier(0);
-        head_step<K + 1>(b0, da, m0_lane, rk_row, first);
+        head_step<K + 1>(b0, da, m0_wave, rk_wave);
     }
 }
 
@@ -100,8 +112,11 @@ __device__ __forceinline__ void body_cols(QuadRows& q, double l1, double l2, con
 
 // steps 0..12 applied to slots 1 and 2 (their rows' columns 0..12 and the trailing columns)
 template <int K>
-__device__ __forceinline__ void body_step(QuadRows& q, const double* m0_row, const double* rk_row) {
+__device__ __forceinline__ void body_step(QuadRows& q, const double* m0_wave, const double* rk_wave) {
     if constexpr (K < QL) {
+        const int lane = fresh_lane();
+        const double* m0_row = m0_wave + (lane >> 4) * (QL * 16);
+        const double* rk_row = rk_wave + (lane >> 4) * 16;
         const double r = rk_row[K];
         const double l1 = -q.r[1][K] * r, l2 = -q.r[2][K] * r;
         const double* m0k = m0_row + K * 16;
@@ -109,7 +124,7 @@ __device__ __forceinline__ void body_step(QuadRows& q, const double* m0_row, con
         asm volatile("s_nop 1");                             // (the column-K registers were FMA results)
         body_cols<K, K + 1>(q, l1, l2, m0k);
         __builtin_amdgcn_sched_barrier(0);
-        body_step<K + 1>(q, m0_row, rk_row);
+        body_step<K + 1>(q, m0_wave, rk_wave);
     }
 }
 
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(WPB * 64, MODE == 0 ? 2 : 3) void k_tri(const doubl
             rank1_head(b0, c1[0], sv[0]);
             DetAcc da;
             da.det = 1.0; da.sign = 0;
-            head_step<0>(b0, da, S.m0 + L.m * QL * 16 + L.t, S.rk + L.m * 16, L.t == 0);
+            head_step<0>(b0, da, S.m0, S.rk);
             // ---- slots 1 and 2
             QuadRows q;
 #pragma unroll
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(WPB * 64, MODE == 0 ? 2 : 3) void k_tri(const doubl
                 __builtin_amdgcn_sched_barrier(0);
             }
             rank1_body(q, c1, sv);
-            body_step<0>(q, S.m0 + L.m * QL * 16, S.rk + L.m * 16);
+            body_step<0>(q, S.m0, S.rk);
             // ---- steps 13..38: the library's code on what is left
             PivotChain ch;
             double l13[QS];
