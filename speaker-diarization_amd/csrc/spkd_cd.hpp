@@ -8,7 +8,7 @@
 // order, accumulating the lower triangle in registers (2x2 blocks, fp64), and
 // leaves a copy P(b) in a per-turn cache for every candidate split point b as the
 // sweep passes it, plus P(c) for the window end in LDS.  A candidate then costs one
-// 10 KB record read and one or two 39x39 symmetric eliminations -- no raw frames,
+// 6.5 KB record read and one or two 39x39 symmetric eliminations -- no raw frames,
 // no edge corrections -- and is re-read, not re-formed, every time the window
 // grows.  Four candidates share a wave (quad layout, spkd_quad.hpp / spkd_tri.hpp).
 // The growing-window decision chain (a float state machine with int() truncation,
