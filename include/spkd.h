@@ -290,6 +290,12 @@ spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t *h_s
                                           const int32_t *h_n_merges, const int32_t *h_a,
                                           const int32_t *h_b, int32_t *h_labels);
 
+/* Host-side: detections per turn of an spkd_gw result -- out[t] = number of non-zero flags
+ * among h_flags[h_off[t] .. h_off[t] + h_n[t]) (the h_win_det entries of turn t's h_n_win[t]
+ * windows; what lies behind them in a reused buffer is not looked at). */
+spkd_status spkd_count_flags(const int32_t *h_flags, const int64_t *h_off, const int32_t *h_n,
+                             int64_t n_groups, int32_t *h_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -932,6 +932,19 @@ spkd_status spkd_labels_from_merges(int64_t n, int64_t n_merges, const int32_t* 
     return SPKD_OK;
 }
 
+spkd_status spkd_count_flags(const int32_t* h_flags, const int64_t* h_off, const int32_t* h_n, int64_t n_groups,
+                             int32_t* h_out) {
+    if (n_groups < 0 || (n_groups > 0 && (!h_flags || !h_off || !h_n || !h_out))) return SPKD_EINVAL;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        if (h_n[g] < 0 || h_off[g] < 0) return SPKD_EINVAL;
+        const int32_t* f = h_flags + h_off[g];
+        int32_t c = 0;
+        for (int32_t i = 0; i < h_n[g]; ++i) c += f[i] != 0;
+        h_out[g] = c;
+    }
+    return SPKD_OK;
+}
+
 spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t* h_seg_off, const int32_t* h_n_merges,
                                           const int32_t* h_a, const int32_t* h_b, int32_t* h_labels) {
     if (n_problems < 0 || (n_problems > 0 && (!h_seg_off || !h_n_merges || !h_a || !h_b || !h_labels)))

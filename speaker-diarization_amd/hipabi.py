@@ -22,7 +22,7 @@ EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_des
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
            'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats', 'spkd_mfcc',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
-           'spkd_labels_from_merges', 'spkd_labels_from_merges_batch']
+           'spkd_labels_from_merges', 'spkd_labels_from_merges_batch', 'spkd_count_flags']
 
 
 class CdParams(C.Structure):
@@ -136,6 +136,7 @@ def load_library(path=None):
     lib.spkd_py2_roundtrip.restype = None
     lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
     lib.spkd_labels_from_merges_batch.argtypes = [i64, vp, vp, vp, vp, vp]
+    lib.spkd_count_flags.argtypes = [vp, vp, vp, i64, vp]
     if lib.spkd_abi_version() != 2:
         raise ImportError('libspkd_hip.so ABI version mismatch')
     if path is None:
@@ -162,6 +163,22 @@ def labels_from_merges(n, a, b):
     st = load_library().spkd_labels_from_merges(n, len(a), _ptr(a), _ptr(b), _ptr(out))
     if st != SPKD_OK:
         raise SpkdError(st, 'bad merge log')
+    return out
+
+
+def count_flags(flags, off, n):
+    """out[t] = number of non-zero flags among flags[off[t] : off[t] + n[t]] (host side)."""
+    flags = np.ascontiguousarray(flags, dtype=np.int32)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    if len(off) != len(n):
+        raise SpkdError(SPKD_EINVAL, 'one offset per group')
+    if len(n) and (int((off + n).max()) > len(flags) or int(n.min()) < 0 or int(off.min()) < 0):
+        raise SpkdError(SPKD_EINVAL, 'flag ranges outside the array')
+    out = np.zeros(len(n), dtype=np.int32)
+    st = load_library().spkd_count_flags(_ptr(flags), _ptr(off), _ptr(n), len(n), _ptr(out))
+    if st != SPKD_OK:
+        raise SpkdError(st, 'bad flag ranges')
     return out
 
 
