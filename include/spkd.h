@@ -296,6 +296,23 @@ spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t *h_s
 spkd_status spkd_count_flags(const int32_t *h_flags, const int64_t *h_off, const int32_t *h_n,
                              int64_t n_groups, int32_t *h_out);
 
+/* Host-side: the recipe lines of an spkd_gw result in recipe order -- per turn its h_n_det[t]
+ * detections (detection j: [start, start + maxi) of the turn, event slot h_off[t] + j), then
+ * the tail line [final start, turn end) -- as the change-detection script writes them
+ * (spk-change-detection.py:374-392): h_times[2 i], h_times[2 i + 1] = start / end in seconds,
+ * start_s + frames / rate in the reference's operation order, passed through
+ * spkd_py2_roundtrip when text_contract is non-zero.  Optional (NULL to skip): the absolute
+ * frame range [h_frame_b[i], h_frame_e[i]) whose statistics the fused detector left for the
+ * line, the event slot h_index[i] of that record, the turn h_line_turn[i] of the line.
+ * n_lines must be n_turns + the sum of h_n_det. */
+spkd_status spkd_gw_lines(int64_t n_turns, const int64_t *h_off, const int32_t *h_n_det,
+                          const double *h_det_start, const double *h_det_maxi,
+                          const double *h_final_start, const double *h_turn_start_s,
+                          const double *h_turn_end_s, const int64_t *h_turn_begin,
+                          const int64_t *h_turn_end, double rate, int text_contract,
+                          int64_t n_lines, double *h_times, int64_t *h_frame_b,
+                          int64_t *h_frame_e, int64_t *h_index, int32_t *h_line_turn);
+
 #ifdef __cplusplus
 }
 #endif

@@ -945,6 +945,46 @@ spkd_status spkd_count_flags(const int32_t* h_flags, const int64_t* h_off, const
     return SPKD_OK;
 }
 
+#pragma clang fp contract(off)
+spkd_status spkd_gw_lines(int64_t n_turns, const int64_t* h_off, const int32_t* h_n_det, const double* h_det_start,
+                          const double* h_det_maxi, const double* h_final_start, const double* h_turn_start_s,
+                          const double* h_turn_end_s, const int64_t* h_turn_begin, const int64_t* h_turn_end,
+                          double rate, int text_contract, int64_t n_lines, double* h_times, int64_t* h_frame_b,
+                          int64_t* h_frame_e, int64_t* h_index, int32_t* h_line_turn) {
+    if (n_turns < 0 || n_lines < 0) return SPKD_EINVAL;
+    if (n_turns > 0 && (!h_off || !h_n_det || !h_det_start || !h_det_maxi || !h_final_start || !h_turn_start_s ||
+                        !h_turn_end_s || !h_turn_begin || !h_turn_end || !h_times))
+        return SPKD_EINVAL;
+    int64_t i = 0;
+    for (int64_t t = 0; t < n_turns; ++t) {
+        const int64_t nd = h_n_det[t];
+        if (nd < 0 || i + nd + 1 > n_lines) return SPKD_EINVAL;
+        const double ls = h_turn_start_s[t], le = h_turn_end_s[t];
+        for (int64_t j = 0; j <= nd; ++j, ++i) {
+            const bool tail = j == nd;
+            double fs, fe;                       // the line's frame positions inside the turn
+            if (tail) {
+                fs = h_final_start[t];
+                h_times[2 * i] = fs / rate + ls;
+                h_times[2 * i + 1] = ((le - ls) * rate) / rate + ls;
+                fe = 0.0;
+            } else {
+                fs = h_det_start[h_off[t] + j];
+                fe = fs + h_det_maxi[h_off[t] + j];
+                h_times[2 * i] = fs / rate + ls;
+                h_times[2 * i + 1] = fe / rate + ls;
+            }
+            if (h_frame_b) h_frame_b[i] = h_turn_begin[t] + (int64_t)fs;
+            if (h_frame_e) h_frame_e[i] = tail ? h_turn_end[t] : h_turn_begin[t] + (int64_t)fe;
+            if (h_index) h_index[i] = h_off[t] + j;
+            if (h_line_turn) h_line_turn[i] = (int32_t)t;
+        }
+    }
+    if (i != n_lines) return SPKD_EINVAL;
+    if (text_contract) spkd_py2_roundtrip(h_times, 2 * n_lines);
+    return SPKD_OK;
+}
+
 spkd_status spkd_labels_from_merges_batch(int64_t n_problems, const int64_t* h_seg_off, const int32_t* h_n_merges,
                                           const int32_t* h_a, const int32_t* h_b, int32_t* h_labels) {
     if (n_problems < 0 || (n_problems > 0 && (!h_seg_off || !h_n_merges || !h_a || !h_b || !h_labels)))

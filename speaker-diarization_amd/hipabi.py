@@ -22,7 +22,7 @@ EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_des
            'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
            'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats', 'spkd_mfcc',
            'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
-           'spkd_labels_from_merges', 'spkd_labels_from_merges_batch', 'spkd_count_flags']
+           'spkd_labels_from_merges', 'spkd_labels_from_merges_batch', 'spkd_count_flags', 'spkd_gw_lines']
 
 
 class CdParams(C.Structure):
@@ -137,6 +137,7 @@ def load_library(path=None):
     lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
     lib.spkd_labels_from_merges_batch.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.spkd_count_flags.argtypes = [vp, vp, vp, i64, vp]
+    lib.spkd_gw_lines.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, dbl, C.c_int, i64, vp, vp, vp, vp, vp]
     if lib.spkd_abi_version() != 2:
         raise ImportError('libspkd_hip.so ABI version mismatch')
     if path is None:
@@ -180,6 +181,34 @@ def count_flags(flags, off, n):
     if st != SPKD_OK:
         raise SpkdError(st, 'bad flag ranges')
     return out
+
+
+def gw_lines(off, n_det, det_start, det_maxi, final_start, turn_start_s, turn_end_s, turn_begin, turn_end,
+             rate, text_contract=True, want_frames=False):
+    """The recipe lines of a gw() result in recipe order (spkd_gw_lines): dict with 'times'
+    [n_lines, 2], 'turn' [n_lines] and, with want_frames, 'frame_b', 'frame_e', 'index'."""
+    c = np.ascontiguousarray
+    off = c(off, dtype=np.int64); n_det = c(n_det, dtype=np.int32)
+    nt = len(n_det)
+    arrs = [c(det_start, dtype=np.float64), c(det_maxi, dtype=np.float64), c(final_start, dtype=np.float64),
+            c(turn_start_s, dtype=np.float64), c(turn_end_s, dtype=np.float64), c(turn_begin, dtype=np.int64),
+            c(turn_end, dtype=np.int64)]
+    if len(off) != nt or any(len(a) != nt for a in arrs[2:]):
+        raise SpkdError(SPKD_EINVAL, 'one entry per turn')
+    if nt and (int(n_det.min()) < 0 or int(off.min()) < 0 or int((off + n_det).max()) > min(len(arrs[0]), len(arrs[1]))):
+        raise SpkdError(SPKD_EINVAL, 'detections outside the event arrays')
+    n_lines = int(n_det.sum(dtype=np.int64)) + nt
+    times = np.empty((n_lines, 2), dtype=np.float64)
+    turn = np.empty(n_lines, dtype=np.int32)
+    fb = np.empty(n_lines, dtype=np.int64) if want_frames else None
+    fe = np.empty(n_lines, dtype=np.int64) if want_frames else None
+    ix = np.empty(n_lines, dtype=np.int64) if want_frames else None
+    p = lambda a: _ptr(a) if a is not None else None
+    st = load_library().spkd_gw_lines(nt, _ptr(off), _ptr(n_det), *[_ptr(a) for a in arrs], float(rate),
+                                      1 if text_contract else 0, n_lines, _ptr(times), p(fb), p(fe), p(ix), _ptr(turn))
+    if st != SPKD_OK:
+        raise SpkdError(st, 'bad growing-window result')
+    return {'times': times, 'turn': turn, 'frame_b': fb, 'frame_e': fe, 'index': ix}
 
 
 def labels_from_merges_batch(seg_off, n_merges, a, b):

@@ -92,37 +92,16 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     nt = len(tb)
     # detections per turn = ones among the turn's n_win window flags (what lies behind them
     # in the reused buffers is not looked at)
-    nd = hipabi.count_flags(r['win_det'], off[:-1], r['n_win']).astype(np.int64)
-    # detection j of turn t sits at off[t] + j
-    tot = int(nd.sum())
-    det_turn = np.repeat(np.arange(nt), nd)
-    first = np.cumsum(nd) - nd
-    idx = off[det_turn] + (np.arange(tot) - first[det_turn])
-    d_start = r['det_start'][idx]
-    d_end = d_start + r['det_maxi'][idx]
-    # values in recipe order: per turn its detections, then the tail line
-    n_lines = nd + 1
-    line_turn = np.repeat(np.arange(nt), n_lines)
-    lfirst = np.cumsum(n_lines) - n_lines
-    is_tail = (np.arange(int(n_lines.sum())) - lfirst[line_turn]) == nd[line_turn]
-    t0 = np.empty(len(line_turn)); t1 = np.empty(len(line_turn))
-    t0[~is_tail] = d_start / rate + ls[det_turn]
-    t1[~is_tail] = d_end / rate + ls[det_turn]
-    t0[is_tail] = r['final_start'] / rate + ls
-    t1[is_tail] = ((le - ls) * rate) / rate + ls
+    nd = hipabi.count_flags(r['win_det'], off[:-1], r['n_win'])
+    # recipe order: per turn its detections (detection j of turn t sits at off[t] + j), then the
+    # tail line; times as the script computes them, through the 12-digit text round trip
+    lines = hipabi.gw_lines(off[:-1], nd, r['det_start'], r['det_maxi'], r['final_start'], ls, le, tb, te, rate,
+                            text_contract=text_contract, want_frames=fused is not None)
+    rt, line_turn = lines['times'], lines['turn']
     if fused is not None:
         # the frames each record covers: [int(start), int(start + maxi)) of the turn for a
         # detection, [int(final start), turn end) for the tail
-        fb = np.empty(len(line_turn), dtype=np.int64); fe = np.empty(len(line_turn), dtype=np.int64)
-        fb[~is_tail] = tb[det_turn] + d_start.astype(np.int64)
-        fe[~is_tail] = tb[det_turn] + d_end.astype(np.int64)
-        fb[is_tail] = tb + r['final_start'].astype(np.int64)
-        fe[is_tail] = te
-        index = off[line_turn] + (np.arange(len(line_turn)) - lfirst[line_turn])
-        fused.append(FusedStats(seg_buf['p'], seg_buf['n'], index, fb, fe))
-    rt = np.stack([t0, t1], axis=1)
-    if text_contract:
-        rt = hipabi.py2_roundtrip(rt.ravel()).reshape(-1, 2)
+        fused.append(FusedStats(seg_buf['p'], seg_buf['n'], lines['index'], lines['frame_b'], lines['frame_e']))
     line_file = owner[line_turn]
     bounds = np.searchsorted(line_file, np.arange(len(files) + 1))
     out = [rt[bounds[i]:bounds[i + 1]] for i in range(len(files))]

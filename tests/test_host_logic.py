@@ -206,3 +206,45 @@ def test_labels_from_merges_batch_matches_the_replay():
         o, nm = int(seg_off[p]), int(n_merges[p])
         one = hipabi.labels_from_merges(n, a_all[o:o + nm], b_all[o:o + nm])
         assert np.array_equal(one, want[o:o + n])
+
+
+def test_gw_lines_helper_matches_the_vectorised_restatement():
+    """spkd_count_flags / spkd_gw_lines (host-side helpers of the batch pipeline) against the
+    numpy expressions they replaced: same doubles, same frame ranges, same order."""
+    hipabi = pkg('hipabi')
+    rng = np.random.default_rng(77)
+    nt, rate = 300, 125.0
+    cap = rng.integers(3, 40, nt)
+    off = np.zeros(nt + 1, dtype=np.int64)
+    off[1:] = np.cumsum(cap)
+    n_win = np.array([rng.integers(0, c + 1) for c in cap], dtype=np.int32)
+    flags = rng.integers(-3, 4, int(off[-1])).astype(np.int32)          # garbage behind the windows included
+    for t in range(nt):
+        flags[off[t]:off[t] + n_win[t]] = rng.integers(0, 2, n_win[t])
+    nd = hipabi.count_flags(flags, off[:-1], n_win)
+    assert nd.tolist() == [int(flags[off[t]:off[t] + n_win[t]].sum()) for t in range(nt)]
+    det_start = rng.uniform(0, 5000, int(off[-1]))
+    det_maxi = rng.uniform(50, 900, int(off[-1])) + rng.integers(0, 2, int(off[-1])) * 0.5
+    final_start = rng.uniform(0, 6000, nt)
+    ls = np.round(rng.uniform(0, 3000, nt), 3)
+    le = ls + np.round(rng.uniform(1, 60, nt), 3)
+    tb = rng.integers(0, 10 ** 8, nt).astype(np.int64)
+    te = tb + rng.integers(100, 8000, nt)
+    for text in (True, False):
+        got = hipabi.gw_lines(off[:-1], nd, det_start, det_maxi, final_start, ls, le, tb, te, rate,
+                              text_contract=text, want_frames=True)
+        times, turn, fb, fe, ix = [], [], [], [], []
+        for t in range(nt):
+            for j in range(int(nd[t])):
+                s = det_start[off[t] + j]
+                e = s + det_maxi[off[t] + j]
+                times.append((s / rate + ls[t], e / rate + ls[t]))
+                fb.append(tb[t] + int(s)); fe.append(tb[t] + int(e)); ix.append(off[t] + j); turn.append(t)
+            times.append((final_start[t] / rate + ls[t], ((le[t] - ls[t]) * rate) / rate + ls[t]))
+            fb.append(tb[t] + int(final_start[t])); fe.append(te[t]); ix.append(off[t] + int(nd[t])); turn.append(t)
+        want = np.array(times)
+        if text:
+            want = hipabi.py2_roundtrip(want.ravel()).reshape(-1, 2)
+        assert np.array_equal(got['times'], want)
+        assert got['turn'].tolist() == turn and got['frame_b'].tolist() == fb and got['frame_e'].tolist() == fe
+        assert got['index'].tolist() == ix
