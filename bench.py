@@ -241,50 +241,19 @@ def main():
         return deliver(compute(0, tm))
 
     def run_steps(k_steps, tm, lanes_=None):
-        """k_steps passes, at most one per lane in flight; the gathers run on this thread in
-        step order (collectives must be issued in the same order on every rank)."""
-        depth = len(lanes_ or lanes)
-        if depth == 1 or k_steps <= 1:
-            out_ = None
-            for _ in range(k_steps):
-                out_ = step(tm)
-            return out_
-        import threading
-        results = [None] * k_steps
-        done = [threading.Event() for _ in range(k_steps)]
-        tms = [{} for _ in range(depth)]
-        nxt = [0]
-        lock = threading.Lock()
-        failure = []
+        """k_steps passes, at most one per lane in flight (pipeline.in_flight); the gathers run
+        on this thread in step order (collectives must be issued in the same order on every
+        rank)."""
+        use = lanes_ or lanes
+        tms = [{} for _ in use]
+        lane_of = {id(c): i for i, c in enumerate(use)}
 
-        def worker(lane):
-            while True:
-                with lock:
-                    k = nxt[0]
-                    nxt[0] += 1
-                if k >= k_steps:
-                    return
-                try:
-                    results[k] = compute(lane, tms[lane], lanes_)
-                except BaseException as e:           # surfaces on the main thread
-                    failure.append(e)
-                finally:
-                    done[k].set()
+        def job(c, k):
+            return pipeline.diarize_batch(c, ptr, total, files, cl=cl, timings=tms[lane_of[id(c)]], fused=fused)
 
-        th = [threading.Thread(target=worker, args=(lane,)) for lane in range(depth)]
-        for t_ in th:
-            t_.start()
         out_ = None
-        for k in range(k_steps):
-            done[k].wait()
-            if failure:
-                break
-            out_ = deliver(results[k])
-            results[k] = None
-        for t_ in th:
-            t_.join()
-        if failure:
-            raise failure[0]
+        for rows in pipeline.in_flight(use, k_steps, job):
+            out_ = deliver(rows)
         for lane_tm in tms:                          # per-launch kernel times of all lanes
             for key, v in lane_tm.items():
                 if isinstance(v, list):

@@ -249,3 +249,54 @@ def _cluster_and_order(ctx, d_frames, total_frames, files, segs, rate, cl, timin
     bounds[1:] = np.cumsum(cnt)
     out = [rows[bounds[i]:bounds[i + 1]] for i in range(len(segs))]
     return out
+
+
+def in_flight(contexts, n_jobs, job):
+    """Runs job(ctx, k) for k = 0 .. n_jobs - 1 with one job in flight per context -- a host
+    thread per context, each taking the next k when it is free -- and yields the results in
+    order of k.  With two contexts on streams of their own the host part of one batch (recipe
+    text, label replay) runs under the kernels of the next, and the tail of one launch beside
+    the head of the next: + 5 - 10 % throughput on 256-hour batches (DESIGN.md par. 5).  A
+    context is only ever used by its own thread; an exception in a job is re-raised here."""
+    import threading
+    if len(contexts) == 1 or n_jobs <= 1:
+        for k in range(n_jobs):
+            yield job(contexts[0], k)
+        return
+    results = [None] * n_jobs
+    done = [threading.Event() for _ in range(n_jobs)]
+    nxt = [0]
+    lock = threading.Lock()
+    failure = []
+
+    def worker(ctx):
+        while not failure:
+            with lock:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= n_jobs:
+                return
+            try:
+                results[k] = job(ctx, k)
+            except BaseException as e:               # surfaces on the consuming thread
+                failure.append(e)
+            finally:
+                done[k].set()
+
+    threads = [threading.Thread(target=worker, args=(c,)) for c in contexts]
+    for th in threads:
+        th.start()
+    try:
+        for k in range(n_jobs):
+            done[k].wait()
+            if failure:
+                break
+            r, results[k] = results[k], None
+            yield r
+    finally:
+        if not failure:
+            failure.append(None)                     # (an abandoned run: the workers stop after their current job)
+        for th in threads:
+            th.join()
+    if failure and failure[0] is not None:
+        raise failure[0]

@@ -248,3 +248,29 @@ def test_gw_lines_helper_matches_the_vectorised_restatement():
         assert np.array_equal(got['times'], want)
         assert got['turn'].tolist() == turn and got['frame_b'].tolist() == fb and got['frame_e'].tolist() == fe
         assert got['index'].tolist() == ix
+
+
+def test_in_flight_keeps_order_and_surfaces_errors():
+    """pipeline.in_flight: one job per context at a time, results in job order, a job's
+    exception re-raised to the consumer (contexts faked: no GPU involved)."""
+    import threading
+    import time
+    pl = pkg('pipeline')
+    users = {}
+
+    def job(ctx, k):
+        users.setdefault(ctx, set()).add(threading.get_ident())
+        time.sleep(0.005 * (3 - k % 3))
+        return k * k
+
+    assert list(pl.in_flight(['A', 'B'], 9, job)) == [k * k for k in range(9)]
+    assert set(users) == {'A', 'B'} and all(len(v) == 1 for v in users.values())    # a context stays with its thread
+    assert list(pl.in_flight(['A'], 3, lambda c, k: (c, k))) == [('A', 0), ('A', 1), ('A', 2)]
+
+    def bad(ctx, k):
+        if k == 2:
+            raise ValueError('boom')
+        return k
+
+    with pytest.raises(ValueError):
+        list(pl.in_flight(['A', 'B'], 6, bad))
