@@ -411,14 +411,20 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
 struct SweepOut {
     long long pos;       // where the persistent sums stand now
     double next_i;       // i value of the next candidate to build
+    long long built_k;   // cache records [0, built_k) exist
 };
 
-// coarse scan: P(b_k) -> cache record k for the new candidates k in [built_k, C)
-// (candidate k sits at (long long)(start + i_k), i_k by repeated addition of istep),
-// the persistent sums parked at the last of them, then P(c) -> LDS.
+// coarse scan: the sweep runs from where it stands to the window end c, leaving P(b_k) in
+// cache record k for every candidate position it passes (candidate k sits at
+// (long long)(start + i_k), i_k by repeated addition of istep) and P(c) in LDS, and rests at
+// c.  The candidates of THIS scan end minfeas frames before c; the handful behind them are
+// the first ones of the next scan and are left now, on the way -- the sweep never walks a
+// frame twice inside an epoch (resting at the scan's last candidate, as it used to, it
+// re-walked the last minfeas frames of the window in every scan).  What a detection makes
+// of the records built ahead is nothing: the next epoch starts from slot 0.
 __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, double* __restrict__ cache,
                                                  double start, double istep, double built_i,
-                                                 long long built_k, long long C, long long sweep_pos,
+                                                 long long built_k, long long cap, long long sweep_pos,
                                                  long long c, int* err) {
     extern __shared__ double gw_lds[];
     double* ldsEnd = gw_lds;
@@ -431,25 +437,27 @@ __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, d
     double acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = persist[e * GW_TPB + tid];
-    const long long want = built_k < C ? (long long)(start + built_i) : c;
-    gw_sweep(gfr, xs, SL, tid, acc, sweep_pos, want, c, [&](long long pos) -> long long {
-        if (built_k < C) {
+    // position of candidate built_k, c when it lies at or behind the window end (or no slot is left)
+    auto next_stop = [&]() -> long long {
+        const long long b = built_k < cap ? (long long)(start + built_i) : c;
+        return b < c ? b : c;
+    };
+    gw_sweep(gfr, xs, SL, tid, acc, sweep_pos, next_stop(), c, [&](long long pos) -> long long {
+        if (pos < c) {                      // a candidate position
             sweep_dump_packed(gcache + built_k * REC, SL, acc);
             ++built_k;
             built_i += istep;
-            if (built_k == C) {             // the sweep rests here until the window grows
-#pragma unroll
-                for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = acc[e];
-                sweep_pos = pos;
-            }
-            return built_k < C ? (long long)(start + built_i) : c;
+            return next_stop();
         }
-        sweep_dump_lds(ldsEnd, SL, acc);    // pos == c
+        sweep_dump_lds(ldsEnd, SL, acc);    // pos == c: the window end; the sweep rests here
+#pragma unroll
+        for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = acc[e];
         return -1;
     }, err);
     SweepOut o;
-    o.pos = sweep_pos;
+    o.pos = c;
     o.next_i = built_i;
+    o.built_k = built_k;
     return o;
 }
 
@@ -794,11 +802,11 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             const double start = S.start;
             const long long a = (long long)start, c = (long long)S.end;
             SweepOut so;
-            so.pos = 0; so.next_i = 0.0;
+            so.pos = 0; so.next_i = 0.0; so.built_k = 0;
             const long long C = S.C, built_k = S.built_k;
             const bool coarse = !S.fine;
             if (coarse) {
-                so = gw_sweep_coarse(fr, cache, start, istep, S.built_i, built_k, C, S.sweep_pos, c, err);
+                so = gw_sweep_coarse(fr, cache, start, istep, S.built_i, built_k, cap, S.sweep_pos, c, err);
             } else {
                 const long long best_k = S.best_k;
                 if (best_k >= 2)
@@ -808,7 +816,10 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                     gw_sweep_fine(fr, cache, nullptr, a, start, S.fine_i0, S.F, C, err);
             }
             __syncthreads();             // everybody has read its arguments; the records are visible
-            if (tid == 0 && coarse && built_k < C) { S.sweep_pos = so.pos; S.built_i = so.next_i; S.built_k = C; }
+            if (tid == 0 && coarse) {
+                S.sweep_pos = so.pos; S.built_i = so.next_i; S.built_k = so.built_k;
+                if (so.built_k < C) { atomicOr(err, ERR_SWEEP); }        // (cannot happen: every candidate of the scan lies before c)
+            }
         }
         GW_TICK(1);
         // ---- (C) the scan's matrices
