@@ -698,6 +698,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     double* persist = gw_lds + TREC;                 // [4][GW_TPB]: the sweep's sums at sweep_pos
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
+    __shared__ double s_common[2];
     __shared__ GwState S;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
@@ -932,22 +933,39 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         BestD best;
         {
             const double N = (double)(c - a);
-            const double ldS = kind == SPKD_BIC ? log(s_ldS) : 0.0;      // s_ldS, c_left, c_x, c_w hold determinants
-            const double corr = pen_w * log(N);
+            // the window's two common terms are one thread's work (the last wave has no
+            // candidates in a typical scan and runs beside the first one's logs); the others
+            // pick them up behind a barrier, with their own logs already taken
+            if (tid == GW_TPB - 1) {
+                s_common[0] = kind == SPKD_BIC ? log(s_ldS) : 0.0;      // s_ldS, c_left, c_x, c_w hold determinants
+                s_common[1] = pen_w * log(N);
+            }
             const int nw = S.nw;
             best.d = fine ? S.maxd : NEG_MAXINT_M1;
             best.k = -1;
-            for (long long k = tid; k < count; k += GW_TPB) {
-                const long long slot = base + k;
-                const double ik = c_i[slot];
+            // (a workgroup-uniform trip count: the barrier sits inside the loop)
+            for (long long k0 = 0; k0 < count || k0 == 0; k0 += GW_TPB) {
+                const long long k = k0 + tid;
+                const bool on = k < count;
+                const long long slot = base + (on ? k : 0);
+                const double ik = on ? c_i[slot] : 0.0;
                 const long long b = (long long)(start + ik);
                 const double n1 = (double)(b - a), n2 = (double)(c - b);
-                double d = c_x[slot];
+                double d = on ? c_x[slot] : 1.0;
+                double lgL = 0.0, lgR = 0.0, lgW = 0.0;
+                if (on && kind != SPKD_KL2) {
+                    lgL = log(c_left[slot]);
+                    lgR = log(d);
+                    if (kind == SPKD_GLR) lgW = log(c_w[slot]);
+                }
+                if (k0 == 0) __syncthreads();                          // s_common is there
+                if (!on) continue;
+                const double ldS = s_common[0], corr = s_common[1];
                 if (kind == SPKD_GLR) {
-                    d = -(N / 2.0) * ((n1 / N) * log(c_left[slot]) + (n2 / N) * log(d) - log(c_w[slot]));
+                    d = -(N / 2.0) * ((n1 / N) * lgL + (n2 / N) * lgR - lgW);
                 } else if (kind == SPKD_BIC) {
-                    const double left = 0.5 * n1 * log(c_left[slot]);     // BIC's memoised 0.5 N1 log det S1
-                    d = 0.5 * N * ldS - left - 0.5 * n2 * log(d);
+                    const double left = 0.5 * n1 * lgL;                   // BIC's memoised 0.5 N1 log det S1
+                    d = 0.5 * N * ldS - left - 0.5 * n2 * lgR;
                     d -= corr;
                 }
                 if ((P.trace && !fine) || fabs(d) == __builtin_huge_val()) {
