@@ -26,7 +26,7 @@ What the line carries besides the contract's keys:
   cpu_baseline        oracle/numpy_engine.py (np.cov + det per distance, like the
                       reference) on a bounded sample, this box's host cores
   cpu_baseline_stats  oracle/spkd_oracle.c (fp64 sufficient statistics, the algorithmic
-                      twin of the GPU path) on one thread and on all cores
+                      twin of the GPU path) on one thread and on the job's CPU share (<= 16)
 """
 import argparse
 import hashlib
@@ -144,10 +144,12 @@ def cpu_baseline_stats(args, synth, cli):
     feats, vad, _ = synth.make_session(777, args.seconds, args.speakers)
     out = {'unit': 'hours-audio/s', 'kind': 'port', 'cpu': cpu_info()[0],
            'sample': 'one %.0f s %d-speaker file, CD gw/BIC + CL hi/BIC through oracle/spkd_oracle.c '
-                     '(turns and pair distances spread over OpenMP / host threads)' % (args.seconds, args.speakers)}
+                     '(turns and pair distances spread over OpenMP / host threads); job_cpu_share = the CPUs this '
+                     'job may use on the box, at most 16 (gpurun gives a one-GPU job a 16-CPU share of the host) '
+                     '-- NOT all %d host CPUs' % (args.seconds, args.speakers, os.cpu_count() or 1)}
     with tempfile.TemporaryDirectory() as tmp:
         _write_session(tmp, synth, feats, vad)
-        for key, threads in (('one_thread', 1), ('all_cores', 0)):
+        for key, threads in (('one_thread', 1), ('job_cpu_share', 0)):
             eng = COracleEngine(threads)
             t0 = time.perf_counter()
             _run_scripts(tmp, cli, eng)
@@ -164,17 +166,47 @@ def rows_digest(rows_by_file):
     return h.hexdigest()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process, which has not touched
+    the GPU (torch is not even imported yet), starts N ranks of itself as a FRESH child
+    process tree through torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1), relays what rank 0 prints and exits with the children's code.  Never an
+    exec: the parent stays alive as a plain waiter."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, cwd=os.getcwd())
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch
     import torch.distributed as dist
+    if world != max(1, args.gpus):
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
     if args.share_device:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible); one process per GPU'
+                         % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
@@ -231,11 +263,16 @@ def main():
         """One pass of the hot path over the batch -> rows per local file."""
         return pipeline.diarize_batch((lanes_ or lanes)[lane], ptr, total, files, cl=cl, timings=tm, fused=fused)
 
+    gather_s = []                                    # wall time of each gather on this rank
+
     def deliver(rows):
         if world == 1:
             return {i: r for i, r in enumerate(rows)}
         # the one exchange of the multi-GPU path: finished recipes -> rank 0 (RCCL)
-        return distributed.gather_rows([(rank + world * i, r) for i, r in enumerate(rows)], dist)
+        tg = time.perf_counter()
+        got = distributed.gather_rows([(rank + world * i, r) for i, r in enumerate(rows)], dist)
+        gather_s.append(time.perf_counter() - tg)
+        return got
 
     def step(tm=None):
         return deliver(compute(0, tm))
@@ -295,14 +332,33 @@ def main():
             compute(lane)
     timings = {}
     barrier()
+    del gather_s[:]
     t0 = time.perf_counter()
     out = run_steps(args.steps, timings)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                # this rank's steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
+    ranks_info = None
     if world > 1:
-        tdt = torch.tensor([dt], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
+        # [step time incl. the closing barrier, this rank's own time, its time inside the gathers]
+        mine = torch.tensor([dt, dt_own, sum(gather_s)], device=dev if args.backend == 'nccl' else 'cpu',
+                            dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = np.array([e.cpu().numpy() for e in every])
+        dt = float(every[:, 0].max())
+        k = max(1, args.steps)
+        # a rank's gather time includes waiting for the slowest rank to arrive (compute skew):
+        # the fastest rank's own time minus its gather time is the pure compute of the fastest,
+        # the smallest gather time is the closest to the cost of the exchange itself
+        ranks_info = {'ms_per_step_min': round(1e3 * float(every[:, 1].min()) / k, 3),
+                      'ms_per_step_max': round(1e3 * float(every[:, 1].max()) / k, 3),
+                      'compute_ms_per_step_min': round(1e3 * float((every[:, 1] - every[:, 2]).min()) / k, 3),
+                      'compute_ms_per_step_max': round(1e3 * float((every[:, 1] - every[:, 2]).max()) / k, 3),
+                      'gather_ms': round(1e3 * float(every[0, 2]) / k, 3),
+                      'gather_ms_min_over_ranks': round(1e3 * float(every[:, 2].min()) / k, 3),
+                      'gather_ms_max_over_ranks': round(1e3 * float(every[:, 2].max()) / k, 3)}
     if rank == 0:
         assert out is not None and len(out) == world * args.files, 'recipe gather incomplete'
         if rows_digest(out) != digest0:
@@ -363,7 +419,9 @@ def main():
                                    '(CD -m gw -d BIC -w 1.0 -st 3.0 -dws 0.1 -l 1.0; CL -m hi -l 1.3); %s'
                                    % (args.files, args.seconds, args.speakers, n_distinct,
                                       'frames read once (segment statistics emitted by the change detector)'
-                                      if fused else 'frames read once per stage'),
+                                      if fused else 'frames read once per stage') +
+                                   '; frames RESIDENT IN HBM when the timed region starts: reading the .fea files '
+                                   'and the host-to-device copy are excluded (see value_incl_h2d)',
                        'files_per_gpu': args.files, 'frames_per_file': int(T),
                        'segments_per_step': n_sets,
                        'segments_recomputed_from_frames': timings.get('stats_recomputed', n_sets),
@@ -382,6 +440,9 @@ def main():
             'device_ms_per_step': round(sum(v[0] for v in kernels.values()) + avg('cluster_prep') + avg('reduce_sets'), 3),
             'verified': verified,
         }
+        if ranks_info:
+            res['gather_ms'] = ranks_info['gather_ms']           # rank 0, per step (incl. waiting for the slowest rank)
+            res['ranks'] = ranks_info
         if world == 1 and not args.no_extras and depth == 1:
             # the same job with two batches in flight: a second context on a stream of its own, a
             # host thread per context; the kernels of consecutive batches share the GPU (the tail of

@@ -72,22 +72,27 @@ def test_single_process_gather_is_identity():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_gather_equals_one_rank(tmp_path):
-    """The multi-GPU path of bench.py, driver-style: two fresh child processes started
-    by torch.distributed.run (before anything touches the GPU), one rank each, sharing
-    the box's single GPU (gloo instead of RCCL for that reason).  Rank 0 must have
-    gathered world x files recipes, identical to what one rank produces for the same
-    global file indices."""
+@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+def test_bench_two_ranks_gather_equals_one_rank(tmp_path, launcher):
+    """The multi-GPU path of bench.py, driver-style: two fresh child processes, one rank
+    each, sharing the box's single GPU (gloo instead of RCCL for that reason), started
+    either by `python bench.py --gpus 2` ITSELF (the parent spawns torch.distributed.run
+    before anything touches the GPU) or by torch.distributed.run from outside.  Rank 0
+    must have gathered world x files recipes, identical to what one rank produces for
+    the same global file indices, and the line carries the gather time and the ranks'
+    step times."""
     import subprocess
     import numpy as np
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     common = ['--steps', '1', '--warmup', '0', '--seconds', '120', '--no-cpu-baseline', '--no-extras']
     two = os.path.join(str(tmp_path), 'two.npz')
     one = os.path.join(str(tmp_path), 'one.npz')
-    r2 = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), 'bench.py',
-                         '--gpus', '2', '--backend', 'gloo', '--share-device', '--files', '2',
-                         '--dump-rows', two] + common, cwd=ROOT, env=env, capture_output=True, text=True,
+    head = [sys.executable, 'bench.py'] if launcher == 'self' else [
+        sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), 'bench.py']
+    env.pop('WORLD_SIZE', None)
+    r2 = subprocess.run(head + ['--gpus', '2', '--backend', 'gloo', '--share-device', '--files', '2',
+                                '--dump-rows', two] + common, cwd=ROOT, env=env, capture_output=True, text=True,
                         timeout=600)
     assert r2.returncode == 0, r2.stderr[-3000:]
     r1 = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--files', '4', '--dump-rows', one] + common,
@@ -96,7 +101,27 @@ def test_bench_two_ranks_gather_equals_one_rank(tmp_path):
     import json
     line = json.loads(r2.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['verified']['files_gathered'] == 4
+    assert line['gather_ms'] >= 0.0 and line['ranks']['ms_per_step_max'] >= line['ranks']['ms_per_step_min'] > 0.0
     a, b = np.load(two), np.load(one)
     assert sorted(a.files) == sorted(b.files) == ['f0', 'f1', 'f2', 'f3']
     for k in a.files:
         assert np.array_equal(a[k], b[k]) and len(a[k]) > 3
+
+
+def test_bench_gpus_flag_starts_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks
+    by itself (as child processes, before it touches the GPU).  Without a GPU every rank
+    stops at its own device check: the ranks' message and torchrun's failure report for
+    two local ranks are the evidence that the spawn happened."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip('covered by test_bench_two_ranks_gather_equals_one_rank[self] on a GPU box')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--share-device',
+                        '--files', '1', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-extras'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs an MI355X') >= 2, r.stderr[-2000:]
+    assert 'local_rank: 1' in r.stderr or 'rank      : 1' in r.stderr or '[1]' in r.stderr, r.stderr[-2000:]
