@@ -208,70 +208,127 @@ __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (
 }
 
 // ---------------------------------------------------------------------------
-// The sweep: threads 0..209 own one 2x2 block of the lower triangle of the 40x40
-// augmented matrix each (column-major over the 20x20 block grid).  Per frame a
-// thread reads x[2 bi .. 2 bi + 1] and x[2 bj .. 2 bj + 1] from the float tile and
-// issues four fp64 FMAs.  A block is two pairs of vertically adjacent entries, i.e.
-// two 16-byte pieces of a packed record.
+// The sweep, for a workgroup of NW waves (4: a workgroup per turn when there are few
+// turns; 1: a WAVE per turn when there are thousands -- no wave ever waits at a barrier
+// for a serial phase of its own turn, the SIMD's other wave belongs to another turn).
+// Thread b of the first NBLK owns one BR x BC block of the lower triangle of the 40x40
+// augmented matrix (row-major over the block grid: row block bi has Q (bi + 1) column
+// blocks, Q = BR / BC).  Per frame a thread reads x[BR bi ..] and x[BC bj ..] from the float
+// tile (one vector read each) and issues BR * BC fp64 FMAs.  Every entry is its own chain of
+// FMAs in frame order, so the sums do not depend on the block shape: the variants give
+// bit-identical records.  In a packed record a block's column is BR consecutive doubles.
+//   NW = 4: 2 x 2 blocks, 210 threads    NW = 2: 4 x 2, 110    NW = 1: 4 x 4, 55
 // ---------------------------------------------------------------------------
-constexpr int GW_WAVES = 4;
-constexpr int GW_TPB = GW_WAVES * WAVE;
 constexpr int ERR_SWEEP = 16;                                // internal: a wanted position behind the sweep
-// pointer to global memory in a non-kernel function: a plain pointer there is generic,
-// its loads and stores are flat_* and count in lgkmcnt too, so every LDS wait of the
-// accumulation would also wait for the tile prefetch and the record dumps in flight
-#define SPKD_GLOBAL __attribute__((address_space(1)))
-constexpr int SW_BLOCKS = 210;
-constexpr int GW_TILE = 128;                                 // frames per LDS tile (float [128][40])
+
+template <int NW> struct GwShape;
+template <> struct GwShape<4> { static constexpr int BR = 2, BC = 2, TILE = 128; };
+template <> struct GwShape<2> { static constexpr int BR = 4, BC = 2, TILE = 64; };
+template <> struct GwShape<1> { static constexpr int BR = 4, BC = 4, TILE = 32; };
+
+template <int NW>
+struct Gw {
+    static constexpr int WAVES = NW;
+    static constexpr int TPB = NW * WAVE;
+    static constexpr int BR = GwShape<NW>::BR, BC = GwShape<NW>::BC;
+    static constexpr int Q = BR / BC, RB = DA / BR;
+    static constexpr int NBLK = Q * RB * (RB + 1) / 2;           // blocks = active threads of the sweep
+    static constexpr int NACC = BR * BC;
+    static constexpr int TILE = GwShape<NW>::TILE;               // frames per LDS tile (float [TILE][40])
+    static constexpr int STAGE = (TILE * D + TPB - 1) / TPB;     // floats per thread per tile
+    // dynamic LDS: P(c) tri record | float frame tile | the pooled window's determinant
+    static constexpr int LDS_POOLED_AT = TREC + TILE * DA / 2;   // (in doubles)
+    static constexpr int LDS_BYTES = TREC * 8 + TILE * DA * 4 + 16;
+    static_assert(BR % BC == 0 && DA % BR == 0 && NBLK <= TPB && TILE <= TPB, "sweep shape");
+};
+
+template <int N> struct FloatVec;
+template <> struct FloatVec<2> { using type = float2; };
+template <> struct FloatVec<4> { using type = float4; };
+template <int N>
+__device__ __forceinline__ void load_fv(const float* p, float (&o)[N]) {
+    const typename FloatVec<N>::type v = *reinterpret_cast<const typename FloatVec<N>::type*>(p);
+    o[0] = v.x; o[1] = v.y;
+    if constexpr (N == 4) { o[2] = v.z; o[3] = v.w; }
+}
 
 struct SweepLane {
     int bi, bj;
     bool on;
-    int o0, o1;          // packed-record offsets of (2 bi, 2 bj) and of the block's second column
+    bool diag;           // the block touches the diagonal: entries with row < column are not part of the triangle
 };
 
+template <int NW>
 __device__ __forceinline__ SweepLane sweep_lane(int tid) {
+    using G = Gw<NW>;
     SweepLane s;
-    s.on = tid < SW_BLOCKS;
-    int rem = s.on ? tid : 0, bj = 0;
-    while (rem >= 20 - bj) { rem -= 20 - bj; ++bj; }
-    s.bj = bj;
-    s.bi = bj + rem;
-    const int r0 = 2 * s.bi, j0 = 2 * s.bj;
-    s.o0 = pk_low(r0, j0);
-    // off-diagonal blocks: (r0, j0 + 1), (r0 + 1, j0 + 1); diagonal blocks: only (r0 + 1, j0 + 1)
-    s.o1 = s.bi > s.bj ? pk_low(r0, j0 + 1) : pk_low(r0 + 1, j0 + 1);
+    s.on = tid < G::NBLK;
+    int rem = s.on ? tid : 0, bi = 0;
+    while (rem >= G::Q * (bi + 1)) { rem -= G::Q * (bi + 1); ++bi; }
+    s.bi = bi;
+    s.bj = rem;
+    s.diag = G::BR * bi < G::BC * rem + G::BC - 1;
     return s;
 }
 
-// acc[0..3] = (r0, j0), (r0, j0 + 1), (r0 + 1, j0), (r0 + 1, j0 + 1)
-__device__ __forceinline__ void sweep_dump_lds(double* rec, const SweepLane& SL, const double (&acc)[4]) {
+// acc[u * BC + v] = entry (BR bi + u, BC bj + v)
+template <int NW>
+__device__ __forceinline__ void sweep_dump_lds(double* rec, const SweepLane& SL, const double (&acc)[Gw<NW>::NACC]) {
+    using G = Gw<NW>;
     if (!SL.on) return;
-    const int r0 = 2 * SL.bi, j0 = 2 * SL.bj;
-    rec[tri_slot(r0, j0)] = acc[0];
-    if (SL.bi > SL.bj) rec[tri_slot(r0, j0 + 1)] = acc[1];   // above the diagonal otherwise
-    rec[tri_slot(r0 + 1, j0)] = acc[2];
-    rec[tri_slot(r0 + 1, j0 + 1)] = acc[3];
+#pragma unroll
+    for (int u = 0; u < G::BR; ++u)
+#pragma unroll
+        for (int v = 0; v < G::BC; ++v) {
+            const int r = G::BR * SL.bi + u, j = G::BC * SL.bj + v;
+            if (r >= j) rec[tri_slot(r, j)] = acc[u * G::BC + v];
+        }
 }
 
-__device__ __forceinline__ void sweep_dump_packed(SPKD_GLOBAL double* rec, const SweepLane& SL, const double (&acc)[4]) {
+template <int NW>
+__device__ __forceinline__ void sweep_gather_lds(const double* rec, const SweepLane& SL, double (&acc)[Gw<NW>::NACC]) {
+    using G = Gw<NW>;
+#pragma unroll
+    for (int u = 0; u < G::BR; ++u)
+#pragma unroll
+        for (int v = 0; v < G::BC; ++v) {
+            const int r = G::BR * SL.bi + u, j = G::BC * SL.bj + v;
+            acc[u * G::BC + v] = (SL.on && r >= j) ? rec[tri_slot(r, j)] : 0.0;
+        }
+}
+
+template <int NW>
+__device__ __forceinline__ void sweep_dump_packed(SPKD_GLOBAL double* rec, const SweepLane& SL,
+                                                  const double (&acc)[Gw<NW>::NACC]) {
+    using G = Gw<NW>;
     if (!SL.on) return;
-    rec[SL.o0] = acc[0];
-    rec[SL.o0 + 1] = acc[2];
-    if (SL.bi > SL.bj) {
-        rec[SL.o1] = acc[1];
-        rec[SL.o1 + 1] = acc[3];
+    const int r0 = G::BR * SL.bi, j0 = G::BC * SL.bj;
+    if (!SL.diag) {
+#pragma unroll
+        for (int v = 0; v < G::BC; ++v) {
+            SPKD_GLOBAL double* col = rec + pk_low(r0, j0 + v);
+#pragma unroll
+            for (int u = 0; u < G::BR; ++u) col[u] = acc[u * G::BC + v];
+        }
     } else {
-        rec[SL.o1] = acc[3];
+#pragma unroll
+        for (int v = 0; v < G::BC; ++v)
+#pragma unroll
+            for (int u = 0; u < G::BR; ++u)
+                if (r0 + u >= j0 + v) rec[pk_low(r0 + u, j0 + v)] = acc[u * G::BC + v];
     }
 }
 
-__device__ __forceinline__ void sweep_gather_packed(const SPKD_GLOBAL double* rec, const SweepLane& SL, double (&acc)[4]) {
-    const bool off = SL.bi > SL.bj;
-    acc[0] = rec[SL.o0];
-    acc[2] = rec[SL.o0 + 1];
-    acc[1] = off ? rec[SL.o1] : 0.0;
-    acc[3] = off ? rec[SL.o1 + 1] : rec[SL.o1];
+template <int NW>
+__device__ __forceinline__ void sweep_gather_packed(const SPKD_GLOBAL double* rec, const SweepLane& SL,
+                                                    double (&acc)[Gw<NW>::NACC]) {
+    using G = Gw<NW>;
+    const int r0 = G::BR * SL.bi, j0 = G::BC * SL.bj;
+#pragma unroll
+    for (int v = 0; v < G::BC; ++v)
+#pragma unroll
+        for (int u = 0; u < G::BR; ++u)
+            acc[u * G::BC + v] = (r0 + u >= j0 + v) ? rec[pk_low(r0 + u, j0 + v)] : 0.0;
 }
 
 // Adds the turn frames [pos, ...) to acc in frame order.  `want` is the next
@@ -279,40 +336,42 @@ __device__ __forceinline__ void sweep_gather_packed(const SPKD_GLOBAL double* re
 // by all threads) when the sweep stands at p == want, BEFORE frame p is added, and
 // returns the next wanted position (> p), or -1 to stop.  `limit` bounds the
 // frames that may be staged (the last position that will ever be wanted).
-// Frames go through an LDS tile of GW_TILE frames; the loads of the next tile are
+// Frames go through an LDS tile of TILE frames; the loads of the next tile are
 // issued into registers before the current one is consumed, so their latency is
 // covered by the accumulation.  Contains block-wide barriers.
 #ifdef SPKD_PROFILE
 // phase clocks of k_gw (profiling builds only: make libspkd_hip_prof.so)
 __device__ unsigned long long g_gw_prof[12];
 #endif
-constexpr int GW_STAGE = (GW_TILE * D + GW_TPB - 1) / GW_TPB;     // floats per thread per tile (20)
 
 // (branch-free: out-of-range slots re-read element 0; `t` is the caller's opaque copy
 // of the thread index, so that none of this address arithmetic is hoisted out of the
 // scan loop and kept alive -- i.e. spilled -- across the elimination code)
+template <int NW>
 __device__ __forceinline__ void sweep_issue(const SPKD_GLOBAL float* fr, long long pos, long long limit,
-                                            int t, float (&st)[GW_STAGE]) {
+                                            int t, float (&st)[Gw<NW>::STAGE]) {
+    using G = Gw<NW>;
     const long long left = limit - pos;
-    const int tl = (int)(left < GW_TILE ? (left < 0 ? 0 : left) : GW_TILE);
+    const int tl = (int)(left < G::TILE ? (left < 0 ? 0 : left) : G::TILE);
     const SPKD_GLOBAL float* src = fr + pos * D;
     const int nfl = tl * D;
     if (nfl > 0) {                       // (uniform) nothing left: element 0 would lie behind `limit`
 #pragma unroll
-        for (int u = 0; u < GW_STAGE; ++u) {
-            const int idx = t + u * GW_TPB;
+        for (int u = 0; u < G::STAGE; ++u) {
+            const int idx = t + u * G::TPB;
             st[u] = src[idx < nfl ? idx : 0];
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < GW_STAGE; ++u) st[u] = 0.0f;
+        for (int u = 0; u < G::STAGE; ++u) st[u] = 0.0f;
     }
 }
 
-template <class OnReach>
+template <int NW, class OnReach>
 __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs, const SweepLane& SL,
-                                         int tid, double (&acc)[4], long long pos, long long want,
+                                         int tid, double (&acc)[Gw<NW>::NACC], long long pos, long long want,
                                          long long limit, OnReach on_reach, int* err) {
+    using G = Gw<NW>;
 #ifdef SPKD_PROFILE
     unsigned long long sw_acc[3] = {0ull, 0ull, 0ull};
     unsigned long long sw_t = clock64();
@@ -321,12 +380,12 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
 #define SW_TICK(i) ((void)0)
 #endif
     long long tile0 = pos, tile_end = pos;       // staged frames [tile0, tile_end)
-    int t = tid, bi2 = 2 * SL.bi, bj2 = 2 * SL.bj;
+    int t = tid, bi2 = G::BR * SL.bi, bj2 = G::BC * SL.bj;
     asm volatile("" : "+v"(t), "+v"(bi2), "+v"(bj2));
     const float* xi = xs + bi2;
     const float* xj = xs + bj2;
-    float st[GW_STAGE];
-    sweep_issue(fr, pos, limit, t, st);
+    float st[G::STAGE];
+    sweep_issue<NW>(fr, pos, limit, t, st);
     for (;;) {
         if (pos == want) {
             SW_TICK(0);
@@ -340,44 +399,49 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
             break;
         }
         if (pos >= tile_end) {
-            const int tl = (int)((limit - pos) < GW_TILE ? (limit - pos) : GW_TILE);
+            const int tl = (int)((limit - pos) < G::TILE ? (limit - pos) : G::TILE);
             SW_TICK(0);
             __syncthreads();                     // the previous tile is no longer read
             // (slots beyond tl * D hold element 0: they land in tile rows >= tl, never read)
 #pragma unroll
-            for (int u = 0; u < GW_STAGE; ++u) {
-                const int idx = t + u * GW_TPB;
+            for (int u = 0; u < G::STAGE; ++u) {
+                const int idx = t + u * G::TPB;
                 const int f = idx / D, c = idx - f * D;
-                if (u < GW_STAGE - 1 || idx < GW_TILE * D) xs[f * DA + c] = st[u];
+                if (u < G::STAGE - 1 || idx < G::TILE * D) xs[f * DA + c] = st[u];
             }
-            if (t < GW_TILE) xs[t * DA + D] = 1.0f;
+            if (t < G::TILE) xs[t * DA + D] = 1.0f;
             __syncthreads();
             tile0 = pos;
             tile_end = pos + tl;
-            sweep_issue(fr, tile_end, limit, t, st);         // in flight during the accumulation
+            sweep_issue<NW>(fr, tile_end, limit, t, st);     // in flight during the accumulation
             SW_TICK(2);
         }
         const long long stop = want < tile_end ? want : tile_end;
         const int f0 = (int)(pos - tile0), f1 = (int)(stop - tile0);
+        auto frame = [&](const float (&a)[G::BR], const float (&b)[G::BC]) {
+            double bd[G::BC];
+#pragma unroll
+            for (int v = 0; v < G::BC; ++v) bd[v] = (double)b[v];
+#pragma unroll
+            for (int u = 0; u < G::BR; ++u) {
+                const double au = (double)a[u];
+#pragma unroll
+                for (int v = 0; v < G::BC; ++v) acc[u * G::BC + v] = fma(au, bd[v], acc[u * G::BC + v]);
+            }
+        };
         // the stretch between two coarse candidates is 12 or 13 frames: those run fully
         // unrolled, all LDS reads in flight before the first FMA (one exposed LDS latency
         // per stretch instead of one per group of four frames)
         auto stretch = [&](auto nf) {
             constexpr int NF = decltype(nf)::value;
-            float2 a[NF], b[NF];
+            float a[NF][G::BR], b[NF][G::BC];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                a[f] = *reinterpret_cast<const float2*>(xi + (f0 + f) * DA);
-                b[f] = *reinterpret_cast<const float2*>(xj + (f0 + f) * DA);
+                load_fv<G::BR>(xi + (f0 + f) * DA, a[f]);
+                load_fv<G::BC>(xj + (f0 + f) * DA, b[f]);
             }
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const double a0 = (double)a[f].x, a1 = (double)a[f].y, b0 = (double)b[f].x, b1 = (double)b[f].y;
-                acc[0] = fma(a0, b0, acc[0]);
-                acc[1] = fma(a0, b1, acc[1]);
-                acc[2] = fma(a1, b0, acc[2]);
-                acc[3] = fma(a1, b1, acc[3]);
-            }
+            for (int f = 0; f < NF; ++f) frame(a[f], b[f]);
         };
         if (f1 - f0 == 13) {
             stretch(std::integral_constant<int, 13>());
@@ -386,13 +450,10 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
         } else {
 #pragma unroll 4
             for (int f = f0; f < f1; ++f) {
-                const float2 a = *reinterpret_cast<const float2*>(xi + f * DA);
-                const float2 b = *reinterpret_cast<const float2*>(xj + f * DA);
-                const double a0 = (double)a.x, a1 = (double)a.y, b0 = (double)b.x, b1 = (double)b.y;
-                acc[0] = fma(a0, b0, acc[0]);
-                acc[1] = fma(a0, b1, acc[1]);
-                acc[2] = fma(a1, b0, acc[2]);
-                acc[3] = fma(a1, b1, acc[3]);
+                float a[G::BR], b[G::BC];
+                load_fv<G::BR>(xi + f * DA, a);
+                load_fv<G::BC>(xj + f * DA, b);
+                frame(a, b);
             }
         }
         pos = stop;
@@ -409,7 +470,7 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
 // loop invariants, and every reload (a scratch load, counted with the global stores
 // in vmcnt) waits for the dump stores in flight -- measured: 6 000 cycles per dump.
 struct SweepOut {
-    long long pos;       // where the persistent sums stand now
+    long long pos;       // where the running sums stand now
     double next_i;       // i value of the next candidate to build
     long long built_k;   // cache records [0, built_k) exist
 };
@@ -422,36 +483,42 @@ struct SweepOut {
 // frame twice inside an epoch (resting at the scan's last candidate, as it used to, it
 // re-walked the last minfeas frames of the window in every scan).  What a detection makes
 // of the records built ahead is nothing: the next epoch starts from slot 0.
+// The running sums at the rest position ARE P(c) of the scan before, which sits in LDS:
+// the sweep picks them up there (fresh: a new epoch, the sums start from zero).
+template <int NW>
 __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, double* __restrict__ cache,
                                                  double start, double istep, double built_i,
                                                  long long built_k, long long cap, long long sweep_pos,
-                                                 long long c, int* err) {
+                                                 long long c, int fresh, int* err) {
+    using G = Gw<NW>;
     extern __shared__ double gw_lds[];
     double* ldsEnd = gw_lds;
-    double* persist = gw_lds + TREC;
-    float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
+    float* xs = (float*)(gw_lds + TREC);
     const int tid = threadIdx.x;
-    const SweepLane SL = sweep_lane(tid);
+    const SweepLane SL = sweep_lane<NW>(tid);
     const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
     SPKD_GLOBAL double* gcache = (SPKD_GLOBAL double*)cache;
-    double acc[4];
+    double acc[G::NACC];
+    if (fresh) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = persist[e * GW_TPB + tid];
+        for (int e = 0; e < G::NACC; ++e) acc[e] = 0.0;
+    } else {
+        sweep_gather_lds<NW>(ldsEnd, SL, acc);
+    }
+    __syncthreads();                        // everybody holds its sums before the record is rewritten
     // position of candidate built_k, c when it lies at or behind the window end (or no slot is left)
     auto next_stop = [&]() -> long long {
         const long long b = built_k < cap ? (long long)(start + built_i) : c;
         return b < c ? b : c;
     };
-    gw_sweep(gfr, xs, SL, tid, acc, sweep_pos, next_stop(), c, [&](long long pos) -> long long {
+    gw_sweep<NW>(gfr, xs, SL, tid, acc, sweep_pos, next_stop(), c, [&](long long pos) -> long long {
         if (pos < c) {                      // a candidate position
-            sweep_dump_packed(gcache + built_k * REC, SL, acc);
+            sweep_dump_packed<NW>(gcache + built_k * REC, SL, acc);
             ++built_k;
             built_i += istep;
             return next_stop();
         }
-        sweep_dump_lds(ldsEnd, SL, acc);    // pos == c: the window end; the sweep rests here
-#pragma unroll
-        for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = acc[e];
+        sweep_dump_lds<NW>(ldsEnd, SL, acc);    // pos == c: the window end; the sweep rests here
         return -1;
     }, err);
     SweepOut o;
@@ -464,23 +531,27 @@ __device__ __noinline__ SweepOut gw_sweep_coarse(const float* __restrict__ fr, d
 // fine scan: P at the F single-frame positions (long long)(start + fine_i0 + k)
 // -> cache records first_slot + k, starting from the sums `base` (a cache record, or
 // nullptr for zero) that stand at base_pos.
+template <int NW>
 __device__ __noinline__ void gw_sweep_fine(const float* __restrict__ fr, double* __restrict__ cache,
                                            const double* __restrict__ base, long long base_pos,
                                            double start, double fine_i0, long long F,
                                            long long first_slot, int* err) {
+    using G = Gw<NW>;
     extern __shared__ double gw_lds[];
-    float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
+    float* xs = (float*)(gw_lds + TREC);
     const int tid = threadIdx.x;
-    const SweepLane SL = sweep_lane(tid);
+    const SweepLane SL = sweep_lane<NW>(tid);
     const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
     SPKD_GLOBAL double* gcache = (SPKD_GLOBAL double*)cache;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (base) sweep_gather_packed((const SPKD_GLOBAL double*)base, SL, acc);
+    double acc[G::NACC];
+#pragma unroll
+    for (int e = 0; e < G::NACC; ++e) acc[e] = 0.0;
+    if (base) sweep_gather_packed<NW>((const SPKD_GLOBAL double*)base, SL, acc);
     double fx = fine_i0;
     long long fk = 0;
     const long long last = (long long)(start + (fine_i0 + (double)(F - 1)));
-    gw_sweep(gfr, xs, SL, tid, acc, base_pos, (long long)(start + fx), last, [&](long long) -> long long {
-        sweep_dump_packed(gcache + (first_slot + fk) * REC, SL, acc);
+    gw_sweep<NW>(gfr, xs, SL, tid, acc, base_pos, (long long)(start + fx), last, [&](long long) -> long long {
+        sweep_dump_packed<NW>(gcache + (first_slot + fk) * REC, SL, acc);
         ++fk;
         fx += 1;
         return fk < F ? (long long)(start + fx) : -1;
@@ -488,17 +559,21 @@ __device__ __noinline__ void gw_sweep_fine(const float* __restrict__ fr, double*
 }
 
 // fused mode, tail segment: the moments of the turn frames [from, to) -> one packed record
+template <int NW>
 __device__ __noinline__ void gw_sweep_tail(const float* __restrict__ fr, long long from, long long to,
                                            double* __restrict__ out, int* err) {
+    using G = Gw<NW>;
     extern __shared__ double gw_lds[];
-    float* xs = (float*)(gw_lds + TREC + 4 * GW_TPB);
+    float* xs = (float*)(gw_lds + TREC);
     const int tid = threadIdx.x;
-    const SweepLane SL = sweep_lane(tid);
+    const SweepLane SL = sweep_lane<NW>(tid);
     const SPKD_GLOBAL float* gfr = (const SPKD_GLOBAL float*)fr;
     SPKD_GLOBAL double* gout = (SPKD_GLOBAL double*)out;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    gw_sweep(gfr, xs, SL, tid, acc, from, to, to, [&](long long) -> long long {
-        sweep_dump_packed(gout, SL, acc);
+    double acc[G::NACC];
+#pragma unroll
+    for (int e = 0; e < G::NACC; ++e) acc[e] = 0.0;
+    gw_sweep<NW>(gfr, xs, SL, tid, acc, from, to, to, [&](long long) -> long long {
+        sweep_dump_packed<NW>(gout, SL, acc);
         return -1;
     }, err);
 }
@@ -554,14 +629,42 @@ __device__ __forceinline__ void single_split_matrix(int pass, const double* ldsE
 // two: the launch has GLR items (wave-uniform; the second rank-one term is skipped
 // otherwise).  DPP rows that name the same record (the left and the right item of a
 // new candidate sit side by side) fetch it once: their loads coalesce.
+// The split point b = (long long)(start + ik) is formed HERE, behind the record loads: ik is a
+// global load of the caller's (the candidate's i value), and a pass that needed it before it
+// could issue its record loads waited for two memory round trips, one after the other.
 __device__ __forceinline__ double quad_split_det(int pass, bool two, const double* ldsEnd,
                                                     const double* __restrict__ rec_b,
-                                                    double n1, double n2, const QuadLane& L, int* err) {
+                                                    double ik, double start, long long a, long long c,
+                                                    const QuadLane& L, int* err) {
     QuadRows q;
     double svb[QS];
     PASS_T0();
     int ta = L.t;
     asm volatile("" : "+v"(ta));          // keep the LDS reads out of the callers' loops
+    {
+        // 81 loads in flight, one latency.  One base pointer per 4 KB (the immediate
+        // offset of a global load spans 4 KB; left to itself the compiler builds a
+        // separate address for every load, spills them and serialises the loads)
+        const int t12 = ta < QL ? ta : QL - 1;          // idle lanes 13..15 ride with lane 12
+        const double* rt[2];
+        long long o1 = 512;                 // opaque, so that the bases stay separate registers
+        asm volatile("" : "+v"(o1));
+        rt[0] = rec_b + t12;
+        rt[1] = rt[0] + o1;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+#pragma unroll
+            for (int j = 0; j < tri_cols(s); ++j) {
+                const int e = pk_off(j) + QL * s - j;   // + t12 (in the base)
+                q.r[s][j] = rt[e / 512][e % 512];
+            }
+            const int c = QL * s + t12;                 // this lane's row of slot s
+            svb[s] = rec_b[pk_off(c) + D - c];          // (39, c): the sums entry of column c
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
+    const double n1 = (double)(b - a), n2 = (double)(c - b);
     const double n = n1 + n2;
     double al, ga, k1a, k1c, k2a, k2c, w1, w2;
     // v1 = k1a * s_b + k1c * s_c ;  c1 = w1 * v1  (same for v2, c2)
@@ -589,27 +692,6 @@ __device__ __forceinline__ double quad_split_det(int pass, bool two, const doubl
         k2c = glr ? 1.0 : 0.0;
         w2 = glr ? -b2 : 0.0;
     }
-    {
-        // 81 loads in flight, one latency.  One base pointer per 4 KB (the immediate
-        // offset of a global load spans 4 KB; left to itself the compiler builds a
-        // separate address for every load, spills them and serialises the loads)
-        const int t12 = ta < QL ? ta : QL - 1;          // idle lanes 13..15 ride with lane 12
-        const double* rt[2];
-        long long o1 = 512;                 // opaque, so that the bases stay separate registers
-        asm volatile("" : "+v"(o1));
-        rt[0] = rec_b + t12;
-        rt[1] = rt[0] + o1;
-#pragma unroll
-        for (int s = 0; s < QS; ++s) {
-#pragma unroll
-            for (int j = 0; j < tri_cols(s); ++j) {
-                const int e = pk_off(j) + QL * s - j;   // + t12 (in the base)
-                q.r[s][j] = rt[e / 512][e % 512];
-            }
-            const int c = QL * s + t12;                 // this lane's row of slot s
-            svb[s] = rec_b[pk_off(c) + D - c];          // (39, c): the sums entry of column c
-        }
-    }
     __builtin_amdgcn_sched_barrier(0);
     PASS_LOADED();
     double v1[QS], v2[QS], c1[QS], c2[QS];
@@ -636,8 +718,6 @@ __device__ __forceinline__ double quad_split_det(int pass, bool two, const doubl
     return det;
 }
 
-// dynamic LDS: P(c) tri record | the sweep's persistent accumulators | float frame tile
-constexpr int GW_LDS_BYTES = TREC * 8 + 4 * GW_TPB * 8 + GW_TILE * DA * 4;
 
 // Growing window over one VAD turn per workgroup (spk-change-detection.py:180-288):
 // the whole float state machine runs here; outputs are the per-window events.
@@ -673,10 +753,12 @@ struct GwState {
     long long n_memo;      // coarse candidates [0, n_memo) have their left term memoised
     long long n_written;   // c_i[0 .. n_written) hold the coarse i sequence
     long long C;           // coarse candidates of the current scan
-    // the sweep of this epoch: cache records [0, built_k) exist, the persistent sums stand
-    // at frame sweep_pos; built_i = i value of candidate built_k (the same repeated
-    // addition as cur_i, so the same doubles)
+    // the sweep of this epoch: cache records [0, built_k) exist, the running sums stand
+    // at frame sweep_pos (fresh: nothing added yet; otherwise they are the P(c) in LDS);
+    // built_i = i value of candidate built_k (the same repeated addition as cur_i, so the
+    // same doubles)
     long long built_k, sweep_pos;
+    int fresh;
     long long best_k, F, base, count;
     long long seg_src, seg_dst;    // fused mode: cache slot -> output record of the detection just made
     int nw, nd;
@@ -686,7 +768,8 @@ struct GwState {
     int tail_in_lds;       // the loop ended on a negative scan whose window end is the turn end
 };
 
-__global__ __launch_bounds__(GW_TPB, 2) void k_gw(
+template <int NW>
+__global__ __launch_bounds__(Gw<NW>::TPB, 2) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ cache_all, double* __restrict__ cand_all,
         int32_t* __restrict__ n_win, double* __restrict__ win_maxd, int32_t* __restrict__ win_det,
@@ -695,7 +778,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         long long log_cap, unsigned long long* log_count, int* err) {
     extern __shared__ double gw_lds[];
     double* ldsEnd = gw_lds;                         // P(c), tri record
-    double* persist = gw_lds + TREC;                 // [4][GW_TPB]: the sweep's sums at sweep_pos
+    constexpr int GW_WAVES = NW, GW_TPB = Gw<NW>::TPB;
     __shared__ BestD red[GW_WAVES];
     __shared__ double s_ldS;
     __shared__ double s_common[2];
@@ -720,8 +803,6 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
     for (int e = tid; e < TREC; e += GW_TPB) ldsEnd[e] = 0.0;
     // record 0 is read (times zero) by the pooled item even before it is built
     for (int e = tid; e < REC; e += GW_TPB) cache[e] = 0.0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
 
     const int kind = P.kind;
     const double winsize = P.winsize, winstep = P.winstep, rate = P.rate;
@@ -738,7 +819,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
         S.built_i = minfeas;
         S.maxd = 0.0; S.maxi = 0.0; S.fine_i0 = 0.0;
         S.n_memo = 0; S.n_written = 0; S.C = 0;
-        S.built_k = 0; S.sweep_pos = 0;
+        S.built_k = 0; S.sweep_pos = 0; S.fresh = 1;
         S.best_k = 0; S.F = 0; S.base = 0; S.count = 0;
         S.seg_src = -1; S.seg_dst = -1;
         S.nw = 0; S.nd = 0; S.fine = 0;
@@ -807,18 +888,18 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
             const long long C = S.C, built_k = S.built_k;
             const bool coarse = !S.fine;
             if (coarse) {
-                so = gw_sweep_coarse(fr, cache, start, istep, S.built_i, built_k, cap, S.sweep_pos, c, err);
+                so = gw_sweep_coarse<NW>(fr, cache, start, istep, S.built_i, built_k, cap, S.sweep_pos, c, S.fresh, err);
             } else {
                 const long long best_k = S.best_k;
                 if (best_k >= 2)
-                    gw_sweep_fine(fr, cache, cache + (best_k - 2) * REC, (long long)(start + c_i[best_k - 2]),
+                    gw_sweep_fine<NW>(fr, cache, cache + (best_k - 2) * REC, (long long)(start + c_i[best_k - 2]),
                                   start, S.fine_i0, S.F, C, err);
                 else
-                    gw_sweep_fine(fr, cache, nullptr, a, start, S.fine_i0, S.F, C, err);
+                    gw_sweep_fine<NW>(fr, cache, nullptr, a, start, S.fine_i0, S.F, C, err);
             }
             __syncthreads();             // everybody has read its arguments; the records are visible
             if (tid == 0 && coarse) {
-                S.sweep_pos = so.pos; S.built_i = so.next_i; S.built_k = so.built_k;
+                S.sweep_pos = so.pos; S.built_i = so.next_i; S.built_k = so.built_k; S.fresh = 0;
                 if (so.built_k < C) { atomicOr(err, ERR_SWEEP); }        // (cannot happen: every candidate of the scan lies before c)
             }
         }
@@ -907,10 +988,8 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 // (no candidates at all: the only item is the pooled window; record 0 is still a
                 // finite record of this or an earlier epoch, or zero-initialised scratch)
                 const double ik = count > 0 ? c_i[slot] : 0.0;
-                const long long b = pass == PASS_POOLED ? a : (long long)(start + ik);
-                const double n1 = (double)(b - a), n2 = (double)(c - b);
                 // determinants; their logs are taken in phase (D), one thread per candidate
-                const double v = quad_split_det(pass, glr_kind, ldsEnd, cache + slot * REC, n1, n2, L, err);
+                const double v = quad_split_det(pass, glr_kind, ldsEnd, cache + slot * REC, ik, start, a, c, L, err);
                 if (valid && L.t == 0) {
                     if (pass == PASS_POOLED) s_ldS = v;
                     else if (pass == PASS_RIGHT) c_x[slot] = v;
@@ -1052,6 +1131,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                 S.built_k = 0;
                 S.built_i = minfeas;
                 S.sweep_pos = (long long)nstart;
+                S.fresh = 1;
                 if (nstart + winsize * 2 <= fn) {
                     S.end = nstart + winsize * 2;
                     S.ws = minfeas;
@@ -1061,8 +1141,6 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                     S.go = 0;
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) persist[e * GW_TPB + tid] = 0.0;
         }
         __syncthreads();
         if (fine && seg_stats) {
@@ -1090,7 +1168,7 @@ __global__ __launch_bounds__(GW_TPB, 2) void k_gw(
                     dst[e] = ldsEnd[tri_slot(r, j)];
                 }
             } else {
-                gw_sweep_tail(fr, (long long)S.start, n, dst, err);
+                gw_sweep_tail<NW>(fr, (long long)S.start, n, dst, err);
             }
         }
     }

@@ -19,6 +19,10 @@ constexpr int D = 39;          // feature dimension
 constexpr int DA = 40;         // augmented dimension ([x; 1])
 constexpr int REC = 820;       // packed upper triangle of DA x DA
 constexpr int WAVE = 64;
+// pointer to global memory in a non-kernel function: a plain pointer there is generic,
+// its loads and stores are flat_* and count in lgkmcnt too, so every LDS wait would also
+// wait for the global loads and stores in flight
+#define SPKD_GLOBAL __attribute__((address_space(1)))
 constexpr int REC_PER_LANE = 13;   // ceil(820 / 64)
 
 __host__ __device__ constexpr int pk_off(int r) { return r * DA - (r * (r - 1)) / 2; }
@@ -46,6 +50,15 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {
 }
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ long long uniform_ll(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+template <class T>
+__device__ __forceinline__ T* uniform_p(T* p) { return (T*)uniform_ll((long long)p); }
 
 __device__ __forceinline__ double uniform_d(double v) {
     int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));

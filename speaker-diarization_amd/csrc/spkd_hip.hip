@@ -29,6 +29,7 @@ struct spkd_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool gw_lds_ok = false;
+    int gw_waves = 0;
     std::string err;
     int* d_err = nullptr;
     unsigned long long* d_counter = nullptr;
@@ -162,8 +163,12 @@ static spkd_status create_ctx(int device, void* stream, bool borrow, spkd_ctx** 
     // for the kernel, or every later launch fails -- checked once, reported by spkd_gw
     int lds_max = 0;
     c->gw_lds_ok = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess &&
-                   GW_LDS_BYTES <= lds_max &&
-                   hipFuncSetAttribute((const void*)k_gw, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS_BYTES) == hipSuccess;
+                   Gw<4>::LDS_BYTES <= lds_max &&
+                   hipFuncSetAttribute((const void*)k_gw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<4>::LDS_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)k_gw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<2>::LDS_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)k_gw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<1>::LDS_BYTES) == hipSuccess;
+    // waves per turn of the growing-window kernel: 0 = by the number of turns (gw_impl)
+    if (const char* e = getenv("SPKD_GW_WAVES")) c->gw_waves = atoi(e);
     *out = c;
     return SPKD_OK;
 }
@@ -605,6 +610,8 @@ spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const 
 }  // namespace
 
 namespace {
+// from this many turns on, a wave per turn (2 048 wave slots on the chip at two waves per SIMD)
+constexpr int64_t GW_WAVE_PER_TURN_FROM = 4096;
 spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
                     const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
                     int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
@@ -651,12 +658,21 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
         !d_log || !c->d_counter || !c->d_err)
         return fail(c, SPKD_EHIP, "gw: a device scratch buffer is missing");
     HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
-    TIMED(c, SPKD_T_GW,
-          hipLaunchKernelGGL(k_gw, dim3((unsigned)n_turns), dim3(GW_TPB), GW_LDS_BYTES, c->stream,
-                             d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,
-                             (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,
-                             (double*)d_d3, (double*)d_d4, d_seg_stats, (spkd_cand_log*)d_log, (long long)log_cap,
-                             c->d_counter, c->d_err));
+    // A turn is a serial chain of scans.  With few turns a workgroup of four waves shares a
+    // turn's matrices (latency); with thousands, ONE WAVE per turn keeps every wave of the
+    // chip busy with its own chain (throughput): no wave waits at a barrier for the serial
+    // phases of its turn, the SIMD's other wave belongs to another turn.  The variants give
+    // bit-identical results (same sums, same eliminations, same decisions).
+    int nw = c->gw_waves;
+    if (nw != 1 && nw != 2 && nw != 4) nw = n_turns >= GW_WAVE_PER_TURN_FROM ? 1 : 4;
+#define SPKD_GW_LAUNCH(NW_)                                                                                     \
+    hipLaunchKernelGGL(k_gw<NW_>, dim3((unsigned)n_turns), dim3(Gw<NW_>::TPB), Gw<NW_>::LDS_BYTES, c->stream, \
+                       d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,               \
+                       (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,        \
+                       (double*)d_d3, (double*)d_d4, d_seg_stats, (spkd_cand_log*)d_log, (long long)log_cap,   \
+                       c->d_counter, c->d_err)
+    TIMED(c, SPKD_T_GW, if (nw == 1) SPKD_GW_LAUNCH(1); else if (nw == 2) SPKD_GW_LAUNCH(2); else SPKD_GW_LAUNCH(4));
+#undef SPKD_GW_LAUNCH
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt = 0;
     HIPCHK(c, hipMemcpyAsync(h_n_win, d_i32a, (size_t)n_turns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

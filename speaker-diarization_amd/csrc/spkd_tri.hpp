@@ -183,25 +183,39 @@ struct TriColAhead {
     }
 };
 
+// A hook runs between the steps of an elimination: after_step<K>() is called when step K is
+// complete, i.e. when column K of the matrix (13, 26 or 39 rows of it, by slot) is dead and
+// its registers are free.  The kernels use it to load column K of the NEXT pass's record
+// into exactly those registers (PackedColumns below): a wave then never waits for a pass's
+// record loads, they are in flight under the previous pass's arithmetic.
+struct NoHook {
+    template <int K> __device__ __forceinline__ void after_step() {}
+    __device__ __forceinline__ void redo() {}
+};
+
 template <int K>
 struct TriStepAhead {
     // l: multipliers of step K (ready); piv_k: its pivot (for the determinant)
-    static __device__ __forceinline__ void run(QuadRows& q, DetAcc& da, const double (&l)[QS], double piv_k) {
+    template <class Hook>
+    static __device__ __forceinline__ void run(QuadRows& q, DetAcc& da, const double (&l)[QS], double piv_k, Hook& hook) {
         if constexpr (K + 1 < D) {
             PivotChain ch;
             double ln[QS];
             TriColAhead<K, K + 1, 0>::run(q, l, ch, ln, da, piv_k);
-            TriStepAhead<K + 1>::run(q, da, ln, ch.piv);
+            hook.template after_step<K>();
+            TriStepAhead<K + 1>::run(q, da, ln, ch.piv, hook);
         } else {
             da.det *= piv_k;
             da.sign |= __double2hiint(piv_k);
+            hook.template after_step<K>();
         }
     }
 };
 
 // det (per DPP row) of four symmetric matrices given by their lower triangles.
 // false: some pivot was not a positive finite number (or the product left the range).
-__device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out) {
+template <class Hook>
+__device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out, Hook& hook) {
     DetAcc da;
     da.det = 1.0;
     da.sign = 0;
@@ -209,10 +223,75 @@ __device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out) {
     double l0[QS];
     __builtin_amdgcn_sched_barrier(0);
     chain_rest<0, 0>(q, ch, l0, da, 1.0);                      // the first pivot's chain: nothing to hide it under
-    TriStepAhead<0>::run(q, da, l0, ch.piv);
+    TriStepAhead<0>::run(q, da, l0, ch.piv, hook);
     det_out = da.det;
     return (da.sign >= 0) && (da.det == da.det) && (da.det < __builtin_huge_val());
 }
+
+__device__ __forceinline__ bool tri_det_nopivot(QuadRows& q, double& det_out) {
+    NoHook h;
+    return tri_det_nopivot(q, det_out, h);
+}
+
+// The hook the kernels use: the lower-triangle columns of a PACKED record (SPKD_REC doubles:
+// column j holds rows j .. 39 contiguously from pk_off(j), so the quad load of (slot s,
+// column j) is 13 consecutive doubles at pk_off(j) + 13 s - j + t; lanes of a diagonal block
+// that sit above the diagonal read the previous column's tail, inside the record, into
+// registers nobody reads) -> `dst`, column K after step K; the sums column (three more
+// doubles per lane) comes with column SUMS_AT, late enough to cost no register while the
+// matrix is still large and early enough to have landed when the elimination ends.
+// rt0 = record + t (t = min(lane in the DPP row, 12)), rt1 = rt0 + 512: the immediate offset
+// of a global load spans 4 KB, so two bases reach the whole record.
+struct PackedColumns {
+    static constexpr int SUMS_AT = 2 * QL;
+    const SPKD_GLOBAL double* rt0;
+    const SPKD_GLOBAL double* rt1;
+    QuadRows* dst;
+    double* sums;         // [QS]
+
+    __device__ __forceinline__ void set_record(const double* rec, int t12) {
+        long long o1 = 512;                 // opaque, so that the bases stay separate registers
+        asm volatile("" : "+v"(o1));
+        rt0 = (const SPKD_GLOBAL double*)rec + t12;
+        rt1 = rt0 + o1;
+    }
+    template <int J>
+    __device__ __forceinline__ void column() {
+#pragma unroll
+        for (int s = J / QL; s < QS; ++s) {
+            const int e = pk_off(J) + QL * s - J;       // + t (in the base)
+            dst->r[s][J] = e < 512 ? rt0[e] : rt1[e - 512];
+        }
+    }
+    // (39, c) for this lane's row c = 13 s + t of slot s: record[pk_off(c) + 39 - c]
+    __device__ __forceinline__ void sums_column() {
+        int t = lane_id() & 15;
+        t = t < QL ? t : QL - 1;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const int c = QL * s + t;
+            sums[s] = rt0[pk_off(c) + D - c - t];
+        }
+    }
+    template <int K>
+    __device__ __forceinline__ void after_step() {
+        column<K>();
+        if constexpr (K == SUMS_AT) sums_column();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void redo() { all(); }
+    // the whole record at once (the first pass of a loop: nothing to hide the loads under)
+    template <int J = 0>
+    __device__ __forceinline__ void all() {
+        if constexpr (J < D) {
+            column<J>();
+            all<J + 1>();
+        } else {
+            sums_column();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
 
 // q[s][J] += c[s] * v_J for the lower-triangle columns (v distributed like the rows)
 template <int J>
@@ -235,10 +314,10 @@ struct TriRank1 {
 // The LOG is left to the caller: a wave holds four determinants, so a log taken here costs
 // a full instruction sequence per four values; the kernels take it later, in their dense
 // one-thread-per-candidate phases (same value, same rounding).
-template <class FormSingle>
-__device__ __forceinline__ double tri_det(QuadRows& q, int m, int* err, FormSingle form_single) {
+template <class FormSingle, class Hook>
+__device__ __forceinline__ double tri_det(QuadRows& q, int m, int* err, FormSingle form_single, Hook& hook) {
     double det;
-    const bool ok = tri_det_nopivot(q, det);
+    const bool ok = tri_det_nopivot(q, det, hook);
     const unsigned long long badmask = __ballot(!ok);
     if (badmask) {
 #pragma unroll 1
@@ -249,8 +328,17 @@ __device__ __forceinline__ double tri_det(QuadRows& q, int m, int* err, FormSing
             const double v = det_pivoted_fn(a, err);
             if (m == mi) det = v;
         }
+        // what the hook has loaded is loaded again: nothing of it has to survive the calls
+        // above (156 registers would, in scratch, with the stores on the fast path)
+        hook.redo();
     }
     return det;
+}
+
+template <class FormSingle>
+__device__ __forceinline__ double tri_det(QuadRows& q, int m, int* err, FormSingle form_single) {
+    NoHook h;
+    return tri_det(q, m, err, form_single, h);
 }
 
 template <class FormSingle>

@@ -30,6 +30,49 @@ __global__ __launch_bounds__(512) void k_pairs(const double* __restrict__ qr, in
     const double nA = ldsA[QREC_COUNT_AT];
     const double ldA = ld[a];
     double acc = 0.0;
+    if (MODE == 3) {
+        // bare elimination, packed records, software-pipelined in registers: column K of the
+        // NEXT record is loaded into the registers step K of this elimination has just freed
+        int ta = L.t; asm volatile("" : "+v"(ta));
+        const int t12 = ta < QL ? ta : QL - 1;
+        auto rec_of = [&](int base) -> const double* {
+            int w = base + L.m;
+            w = w < WINDOW ? w : WINDOW - 1;
+            return pk + (size_t)((a + 1 + w) % n_rec) * REC;
+        };
+        QuadRows q, qn; double sv[QS], svn[QS];
+        PackedColumns pc;
+        int base = 4 * wave;
+        const double* P = rec_of(base);
+        pc.dst = &q; pc.sums = sv; pc.set_record(P, t12);
+        pc.all();
+        double cnt = P[REC - 1];
+        for (; base < WINDOW; base += 32) {
+            const double* Pn = rec_of(base + 32 < WINDOW ? base + 32 : base);
+            const double cnt_n = Pn[REC - 1];
+            pc.dst = &qn; pc.sums = svn; pc.set_record(Pn, t12);
+            const double n = nA + cnt;
+            const double f = 1.0 / (n - 1.0);
+            double c1[QS];
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) {
+#pragma unroll
+                for (int j = 0; j < tri_cols(s2); ++j) q.r[s2][j] = f * (ldsA[(s2 * DA + j) * 16 + ta] + q.r[s2][j]);
+                sv[s2] = ldsA[(s2 * DA + D) * 16 + ta] + sv[s2];
+                c1[s2] = -((f / n) * sv[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TriRank1<0>::run(q, c1, sv);
+            double det; tri_det_nopivot(q, det, pc);
+            acc += log(det);
+            q = qn;
+#pragma unroll
+            for (int s2 = 0; s2 < QS; ++s2) sv[s2] = svn[s2];
+            cnt = cnt_n;
+        }
+        if (L.t == 0) out[(size_t)blockIdx.x * WINDOW + wave * 4 + L.m] = acc;
+        return;
+    }
     for (int base = 4 * wave; base < WINDOW; base += 32) {
         int w = base + L.m;
         const bool valid = w < WINDOW;
@@ -147,16 +190,17 @@ int main(int argc, char** argv) {
         hipMemcpy(dL, hld.data(), n_rec * 8, hipMemcpyHostToDevice);
         hipMemset(dErr, 0, 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int mode = 0; mode < 3; ++mode)
+        for (int mode = 0; mode < 4; ++mode)
             for (int it = 0; it < 3; ++it) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k_pairs<0>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)nullptr);
                 else if (mode == 1) hipLaunchKernelGGL(k_pairs<1>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)dP);
-                else hipLaunchKernelGGL(k_pairs<2>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)dP);
+                else if (mode == 2) hipLaunchKernelGGL(k_pairs<2>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)dP);
+                else hipLaunchKernelGGL(k_pairs<3>, dim3(blocks), dim3(512), 0, 0, dE, n_rec, dL, dO, dErr, (const double*)dP);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (it == 2) printf("n_rec %6d  %-34s %.3f ms  %.1f M pairs/s\n", n_rec,
-                                    mode == 0 ? "bare elimination" : (mode == 1 ? "quad_pair_det + log + finish_distance" : "bare elimination, packed records"), ms,
+                                    mode == 0 ? "bare elimination" : (mode == 1 ? "quad_pair_det + log + finish_distance" : (mode == 2 ? "bare elimination, packed records" : "bare, packed, register-pipelined")), ms,
                                     (double)blocks * WINDOW / ms / 1e3);
             }
         hipFree(dP); hipFree(dE); hipFree(dO); hipFree(dL); hipFree(dErr);
