@@ -46,6 +46,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_FRAME = 156          # 39 float32, each frame read once per stage
 BYTES_PER_PAIR = 13128         # two 6 560-B records in, one double out
 REC_BYTES = 6560
+# fp64 work ("report achieved fp64 FLOP/s alongside"): useful multiply-adds,
+# not issued lanes.  A 39x39 symmetric determinant: sum_j j (39 - j) = 9 880 FMAs of
+# elimination + 780 of forming the covariance (the rank-one mean correction) + 780 of the
+# linear combination of the records = 11 440 FMAs = 22 880 flop; a frame added to the
+# running moment sums: 820 FMAs = 1 640 flop.  Peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x
+# 2.4 GHz = 78.6 TFLOP/s (fp64 vector; the fp64 matrix rate is the same on gfx950).
+FLOP_PER_DET = 2 * (9880 + 780 + 780)
+FLOP_PER_FRAME = 2 * 820
+FP64_PEAK_TFLOPS = 78.6
 TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_bench256_hbm_traffic.json')
 
 CD_ARGS = ['-m', 'gw', '-d', 'BIC', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0']
@@ -381,12 +390,21 @@ def main():
             'k_matrix': (avg('matrix'), timings.get('matrix_pairs', 0) * BYTES_PER_PAIR),
             'k_ahc': (avg('ahc'), timings.get('ahc_pairs', 0) * BYTES_PER_PAIR),
         }
+        flops = {
+            'k_gw': timings.get('gw_dets', 0) * FLOP_PER_DET + timings.get('gw_frames', 0) * FLOP_PER_FRAME,
+            'k_chunk_stats': timings.get('stats_frames', 0) * FLOP_PER_FRAME,
+            'k_matrix': timings.get('matrix_pairs', 0) * FLOP_PER_DET,
+            'k_ahc': timings.get('ahc_pairs', 0) * FLOP_PER_DET,
+        }
         dom = max(kernels, key=lambda k: kernels[k][0])
         per_kernel = {}
         for k, (ms, byts) in kernels.items():
             gbs = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+            tfs = (flops[k] / 1e12) / (ms / 1e3) if ms > 0 else 0.0
             per_kernel[k] = {'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(byts),
-                             'achieved_GBps': round(gbs, 2), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 5)}
+                             'achieved_GBps': round(gbs, 2), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 5),
+                             'fp64_flop': int(flops[k]), 'fp64_TFLOPs': round(tfs, 3),
+                             'frac_of_fp64_peak': round(tfs / FP64_PEAK_TFLOPS, 4)}
         dms, dbytes = kernels[dom]
         achieved = (dbytes / 1e9) / (dms / 1e3) if dms > 0 else 0.0
         pair_rate = 0.0
@@ -433,7 +451,11 @@ def main():
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_GBps': round(traffic / 1e9 / (dms / 1e3), 1) if traffic and dms > 0 else None,
-                         'traffic_source': traffic_note},
+                         'traffic_source': traffic_note,
+                         # the same kernel against the fp64 vector peak (useful flop, see FLOP_PER_DET)
+                         'flops': {'achieved': per_kernel[dom]['fp64_TFLOPs'], 'peak': FP64_PEAK_TFLOPS,
+                                   'unit': 'TFLOP/s', 'frac': per_kernel[dom]['frac_of_fp64_peak'],
+                                   'determinants': int(timings.get('gw_dets', 0)) if dom == 'k_gw' else None}},
             'kernels': per_kernel,
             'wall_ms': {k[5:]: round(float(np.mean(v)), 2) for k, v in timings.items() if k.startswith('wall_')},
             'gw_stream_ms': round(avg('gw_stream_ms'), 2),
@@ -465,6 +487,9 @@ def main():
             res['two_batches_in_flight'] = {'value': args.files * (args.seconds / 3600.0) * k2 / dt2,
                                             'unit': 'hours-audio/s', 'steps': k2,
                                             'ms_per_step': round(1e3 * dt2 / k2, 2)}
+        if world == 1 and not args.no_extras and depth == 1:
+            res['value_incl_h2d'] = with_uploads(torch, dev, args, frames, total, files, pipeline, ctx, cl, fused, digest0)
+            res['dropin_scripts_wall_s'] = dropin_wall(args, synth, first_host)
         if world == 1 and not args.no_extras:
             res['hbm_copy_GBps'] = round(copy_rate(torch, dev), 1)
             res['other_configs'] = other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, local)
@@ -474,6 +499,86 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def with_uploads(torch, dev, args, frames, total, files, pipeline, ctx, cl, fused, digest0):
+    """What the headline leaves out, measured: the same steps with every batch coming from
+    PINNED HOST memory.  Two device buffers; the upload of batch k + 1 runs on a copy stream
+    under the kernels of batch k (the library is synchronous to its caller, so the copy is
+    queued before the step starts).  Reading the .fea files from disk is still not in it."""
+    host = torch.empty(frames.shape, dtype=frames.dtype, pin_memory=True)
+    host.copy_(frames)
+    bufs = [frames, torch.empty_like(frames)]
+    copier = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    k = max(4, args.steps)
+
+    def upload(i):
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(copier):
+            bufs[i % 2].copy_(host, non_blocking=True)
+            ev.record(copier)
+        return ev
+
+    out = None
+    t_up0 = time.perf_counter()
+    ev = upload(0)
+    ev.synchronize()
+    t_up = time.perf_counter() - t_up0               # one upload alone
+    t0 = time.perf_counter()
+    ev = upload(0)
+    for i in range(k):
+        main.wait_event(ev)                          # batch i is on the device
+        ev.synchronize()
+        if i + 1 < k:
+            nxt = upload(i + 1)                      # overwrites the buffer batch i - 1 used (its step has returned)
+        rows = pipeline.diarize_batch(ctx, bufs[i % 2].data_ptr(), total, files, cl=cl, fused=fused)
+        out = {j: r for j, r in enumerate(rows)}
+        if i + 1 < k:
+            ev = nxt
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rows_digest(out) != digest0:
+        raise SystemExit('bench.py: the upload-inclusive run produced different rows')
+    gb = host.numel() * 4 / 1e9
+    del bufs[1], host
+    return {'value': args.files * (args.seconds / 3600.0) * k / dt, 'unit': 'hours-audio/s', 'steps': k,
+            'ms_per_step': round(1e3 * dt / k, 2), 'upload_GB_per_step': round(gb, 2),
+            'upload_alone_ms': round(1e3 * t_up, 1), 'h2d_GBps': round(gb / t_up, 1),
+            'note': 'frames from pinned host memory every step, upload of batch k+1 on a copy stream under the '
+                    'kernels of batch k; .fea file reading excluded'}
+
+
+def dropin_wall(args, synth, first_host):
+    """Wall time of the drop-in executables themselves on ONE file, the way spk-diarization2.py
+    runs them (spk-diarization2.py:122-128): two fresh child processes of this one (never an
+    exec), each paying interpreter start, library load, context creation, .fea read and
+    upload.  BASELINE.md: the reference needs ~3 811 s for the same two steps on 1 h."""
+    import subprocess
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        _write_session(tmp, synth, first_host[0], first_host[1])
+        env = dict(os.environ)
+        t0 = time.perf_counter()
+        r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'spk-change-detection.py'), os.path.join(tmp, 'vad.recipe'),
+                             os.path.join(tmp, 'fea') + '/', '-o', os.path.join(tmp, 'spkc.recipe')] + CD_ARGS,
+                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        t1 = time.perf_counter()
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'spk-clustering.py'), os.path.join(tmp, 'spkc.recipe'),
+                             os.path.join(tmp, 'fea') + '/', '-o', os.path.join(tmp, 'out.recipe')] + CL_ARGS,
+                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        t2 = time.perf_counter()
+        if r1.returncode or r2.returncode:
+            return {'error': (r1.stderr + r2.stderr)[-400:]}
+        lines = open(os.path.join(tmp, 'out.recipe')).read().count('\n')
+    out = {'change_detection_s': round(t1 - t0, 3), 'clustering_s': round(t2 - t1, 3), 'total_s': round(t2 - t0, 3),
+           'file_seconds': args.seconds, 'speaker_lines': lines,
+           'xRT': round(args.seconds / (t2 - t0), 1),
+           'note': './spk-change-detection.py + ./spk-clustering.py as child processes on one file '
+                   '(process start, imports, library load, context, .fea read and upload included)'}
+    return out
 
 
 def copy_rate(torch, dev):

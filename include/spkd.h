@@ -69,6 +69,7 @@ spkd_status spkd_malloc(spkd_ctx *ctx, size_t bytes, void **d_ptr);
 spkd_status spkd_free(spkd_ctx *ctx, void *d_ptr);
 spkd_status spkd_memcpy_h2d(spkd_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 spkd_status spkd_memcpy_d2h(spkd_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+spkd_status spkd_memcpy_d2d(spkd_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 
 /* Timing of the most recent call, measured with HIP events recorded on the
  * context's stream around each kernel launch (milliseconds).
@@ -79,6 +80,12 @@ enum {
     SPKD_T_CLUSTER_PREP, SPKD_T_MATRIX, SPKD_T_AHC, SPKD_T_GW, SPKD_T_SW, SPKD_N_TIMERS
 };
 spkd_status spkd_last_kernel_ms(spkd_ctx *ctx, int which, float *ms);
+
+/* Work done by the most recent growing-window call (spkd_gw / spkd_gw_ex / spkd_gw_fused):
+ * the number of 39x39 determinants it evaluated (one per covariance the reference's bic /
+ * glr form at spk-change-detection.py:87-98, 107-115 -- left, right, pooled, within).
+ * For the fp64 figure beside the HBM fraction. */
+spkd_status spkd_last_gw_items(spkd_ctx *ctx, int64_t *items);
 
 /* ---------------------------------------------------------------------------
  * (1) Sufficient statistics of frame sets.
@@ -115,6 +122,19 @@ spkd_status spkd_pair_terms(spkd_ctx *ctx, const double *d_stats,
  * diagonal = 2^63 (sys.maxint as a float).  d_matrix: n*n doubles. */
 spkd_status spkd_distance_matrix(spkd_ctx *ctx, int kind, double lambdac,
                                  const double *d_stats, int64_t n, double *d_matrix);
+
+/* Rows [row_begin, row_end) of that matrix, as spk_cluster_hi's variant `variant` fills them
+ * (a block of the outer loop of spk-clustering.py:188-200 / spk-clustering2.py:178-184):
+ * d_rows[(a - row_begin) * n + c] for c > a is the distance, c == a the diagonal value
+ * (variant 1: 2^63, variant 2: +inf), c < a: +inf for variant 2, UNSPECIFIED for variant 1
+ * (the caller mirrors the upper triangle).  One long file tiled over several GPUs
+ * (SURVEY.md 8(e) row 2): every rank holds all n records, computes its block of rows, the
+ * blocks are gathered, spkd_ahc_matrix runs the merge loop on the assembled matrix.
+ * h_stat_max / h_stat_min (may be NULL): max / min over the finite distances of the block
+ * (NaN: none) -- variant 1's running statistics start from the max / min over all blocks. */
+spkd_status spkd_distance_rows(spkd_ctx *ctx, int variant, int kind, double lambdac,
+                               const double *d_stats, int64_t n, int64_t row_begin, int64_t row_end,
+                               double *d_rows, double *h_stat_max, double *h_stat_min);
 
 /* ---------------------------------------------------------------------------
  * (3) Change detection.
@@ -246,6 +266,16 @@ spkd_status spkd_ahc(spkd_ctx *ctx, const double *d_stats, const int64_t *h_seg_
                      int64_t n_problems, const spkd_ahc_params *params,
                      int32_t *h_n_merges, int32_t *h_merge_a, int32_t *h_merge_b,
                      double *h_merge_d, double *h_stat_max, double *h_stat_min);
+
+/* spkd_ahc for ONE problem of n records whose initial n x n matrix the caller supplies
+ * (d_matrix, device, in exactly the form spkd_ahc would have computed: see
+ * spkd_distance_rows): the merge loop of spk-clustering.py:201-240 alone.  stat_max_in /
+ * stat_min_in: variant 1's running max / min over the distances behind d_matrix (NaN: none);
+ * ignored for variant 2.  Outputs as spkd_ahc's, problem 0. */
+spkd_status spkd_ahc_matrix(spkd_ctx *ctx, const double *d_stats, int64_t n, const spkd_ahc_params *params,
+                            const double *d_matrix, double stat_max_in, double stat_min_in,
+                            int32_t *h_n_merges, int32_t *h_merge_a, int32_t *h_merge_b,
+                            double *h_merge_d, double *h_stat_max, double *h_stat_min);
 
 /* ---------------------------------------------------------------------------
  * (6) Feature front-end: what `feacat -c fconfig.cfg -H --raw-output x.wav` computes for the

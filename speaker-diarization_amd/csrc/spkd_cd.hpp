@@ -971,6 +971,7 @@ __global__ __launch_bounds__(Gw<NW>::TPB, 2) void k_gw(
                 }
                 return true;
             };
+            if (tid == 0) atomicAdd(log_count + 1, (unsigned long long)M);      // work counter (spkd_last_gw_items)
 #ifdef SPKD_PROFILE
             prof_items += (unsigned long long)M;
 #endif

@@ -30,6 +30,8 @@ struct spkd_ctx {
     bool own_stream = false;
     bool gw_lds_ok = false;
     int gw_waves = 0;
+    unsigned long long init_keys[2] = {0ull, ~0ull};
+    int64_t last_gw_items = 0;
     std::string err;
     int* d_err = nullptr;
     unsigned long long* d_counter = nullptr;
@@ -149,7 +151,7 @@ static spkd_status create_ctx(int device, void* stream, bool borrow, spkd_ctx** 
         c->own_stream = true;
     }
     if (hipMalloc(&c->d_err, sizeof(int)) != hipSuccess ||
-        hipMalloc(&c->d_counter, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_counter, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         spkd_destroy(c);
         return SPKD_EHIP;
@@ -232,6 +234,19 @@ spkd_status spkd_memcpy_d2h(spkd_ctx* c, void* h_dst, const void* d_src, size_t 
     if (!c) return SPKD_EINVAL;
     HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPKD_OK;
+}
+
+spkd_status spkd_memcpy_d2d(spkd_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+    if (!c) return SPKD_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SPKD_OK;
+}
+
+spkd_status spkd_last_gw_items(spkd_ctx* c, int64_t* items) {
+    if (!c || !items) return SPKD_EINVAL;
+    *items = c->last_gw_items;
     return SPKD_OK;
 }
 
@@ -323,9 +338,25 @@ struct AhcBuffers {
     unsigned long long* smin;
 };
 
+unsigned long long host_dkey(double v) {                      // dkey() of spkd_cluster.hpp, on the host
+    unsigned long long b;
+    std::memcpy(&b, &v, sizeof b);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// What the initial matrix is: computed here in full (the default), only the rows
+// [row_begin, row_end) of a single problem (spkd_distance_rows: a rank's block of a matrix
+// tiled over several GPUs), or given by the caller (spkd_ahc_matrix: the gathered blocks).
+struct MatrixPlan {
+    const double* d_init = nullptr;
+    double init_max = NAN, init_min = NAN;            // variant 1: max / min over the distances behind d_init
+    int64_t row_begin = -1, row_end = -1;
+};
+
 spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
                         int variant, int kind, double lambdac, AhcBuffers& B, int64_t& n_total,
-                        std::vector<int64_t>& offs, std::vector<int32_t>& prob_of) {     // both must outlive the stream work
+                        std::vector<int64_t>& offs, std::vector<int32_t>& prob_of,      // both must outlive the stream work
+                        const MatrixPlan& plan = MatrixPlan()) {
     n_total = h_seg_off[n_prob];
     offs.clear();                                    // seg_off | mat_off
     offs.insert(offs.end(), h_seg_off, h_seg_off + n_prob + 1);
@@ -351,7 +382,10 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     {
         const int X = 8;
         std::vector<std::vector<int32_t>> lists(X);
-        if (n_prob >= X) {
+        if (plan.row_begin >= 0) {
+            // a block of rows of the one problem: dealt round-robin (every XCD holds the records)
+            for (int64_t r = plan.row_begin; r < plan.row_end; ++r) lists[(size_t)((r - plan.row_begin) % X)].push_back((int32_t)r);
+        } else if (n_prob >= X) {
             std::vector<int64_t> order((size_t)n_prob);
             for (int64_t p = 0; p < n_prob; ++p) order[(size_t)p] = p;
             std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
@@ -394,6 +428,13 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
     B.smin = B.smax + n_prob;
     HIPCHK(c, hipMemsetAsync(B.smax, 0x00, (size_t)n_prob * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(B.smin, 0xff, (size_t)n_prob * sizeof(unsigned long long), c->stream));
+    if (plan.d_init && n_prob == 1) {
+        // (the keys live in the context: the copies are asynchronous)
+        c->init_keys[0] = plan.init_max == plan.init_max ? host_dkey(plan.init_max) : 0ull;
+        c->init_keys[1] = plan.init_min == plan.init_min ? host_dkey(plan.init_min) : ~0ull;
+        HIPCHK(c, hipMemcpyAsync(B.smax, &c->init_keys[0], sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(B.smin, &c->init_keys[1], sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    }
     // a private working copy of the records (clusters are merged in place), expanded to the
     // quad layout the clustering kernels load from
     if ((st = scratch(c, S_AHC_STATS, (size_t)n_total * QREC * sizeof(double), &p)) != SPKD_OK) return st;
@@ -412,12 +453,16 @@ spkd_status ahc_prepare(spkd_ctx* c, const double* d_stats, const int64_t* h_seg
               hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
                                  (const double*)B.ex, n_total, kind, B.ld, B.aux, c->d_err));
         auto kmat = kind == SPKD_GLR ? k_matrix<true> : k_matrix<false>;   // GLR has a second rank-one term
-        TIMED(c, SPKD_T_MATRIX,
-              hipLaunchKernelGGL(kmat, dim3((unsigned)grid_rows), dim3(MX_WAVES * WAVE), 0, c->stream,
-                                 (const double*)B.ex, (const double*)B.pk, (const int64_t*)B.seg_off, (const int32_t*)d_prob,
-                                 (const int32_t*)d_prob + n_total, variant, kind, lambdac,
-                                 (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
-                                 B.smax, B.smin, c->d_err));
+        if (plan.d_init) {
+            HIPCHK(c, hipMemcpyAsync(B.mat, plan.d_init, (size_t)cells * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        } else if (grid_rows > 0) {
+            TIMED(c, SPKD_T_MATRIX,
+                  hipLaunchKernelGGL(kmat, dim3((unsigned)grid_rows), dim3(MX_WAVES * WAVE), 0, c->stream,
+                                     (const double*)B.ex, (const double*)B.pk, (const int64_t*)B.seg_off, (const int32_t*)d_prob,
+                                     (const int32_t*)d_prob + n_total, variant, kind, lambdac,
+                                     (const double*)B.ld, (const double*)B.aux, B.mat, (const int64_t*)B.mat_off,
+                                     B.smax, B.smin, c->d_err));
+        }
     }
     HIPCHK(c, hipGetLastError());
     return SPKD_OK;
@@ -449,9 +494,41 @@ spkd_status spkd_distance_matrix(spkd_ctx* c, int kind, double lambdac, const do
     return end_call(c);
 }
 
+spkd_status spkd_distance_rows(spkd_ctx* c, int variant, int kind, double lambdac, const double* d_stats,
+                               int64_t n, int64_t row_begin, int64_t row_end, double* d_rows,
+                               double* h_stat_max, double* h_stat_min) {
+    if (!c || n < 0 || kind < 0 || kind > 2 || (variant != 1 && variant != 2)) return SPKD_EINVAL;
+    if (row_begin < 0 || row_end < row_begin || row_end > n) return fail(c, SPKD_EINVAL, "distance_rows: bad row block");
+    if (h_stat_max) *h_stat_max = std::nan("");
+    if (h_stat_min) *h_stat_min = std::nan("");
+    if (n == 0 || row_end == row_begin) return SPKD_OK;
+    if (!d_stats || !d_rows) return fail(c, SPKD_EINVAL, "null argument");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    const int64_t seg_off[2] = {0, n};
+    AhcBuffers B;
+    int64_t n_total = 0;
+    std::vector<int64_t> offs;
+    std::vector<int32_t> prob_of;
+    MatrixPlan plan;
+    plan.row_begin = row_begin;
+    plan.row_end = row_end;
+    if ((st = ahc_prepare(c, d_stats, seg_off, 1, variant, kind, lambdac, B, n_total, offs, prob_of, plan)) != SPKD_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(d_rows, B.mat + row_begin * n, (size_t)(row_end - row_begin) * n * sizeof(double),
+                             hipMemcpyDeviceToDevice, c->stream));
+    unsigned long long keys[2] = {0ull, ~0ull};
+    HIPCHK(c, hipMemcpyAsync(&keys[0], B.smax, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&keys[1], B.smin, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    st = end_call(c);
+    if (h_stat_max) *h_stat_max = key_to_double(keys[0], true);
+    if (h_stat_min) *h_stat_min = key_to_double(keys[1], false);
+    return st;
+}
+
 // ------------------------------------------------------------------ (4) AHC
-spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
-                     const spkd_ahc_params* P, int32_t* h_n_merges, int32_t* h_merge_a,
+namespace {
+spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
+                     const spkd_ahc_params* P, const MatrixPlan& plan, int32_t* h_n_merges, int32_t* h_merge_a,
                      int32_t* h_merge_b, double* h_merge_d, double* h_stat_max, double* h_stat_min) {
     if (!c || !P || n_prob < 0) return SPKD_EINVAL;
     if (n_prob == 0) return SPKD_OK;
@@ -469,7 +546,7 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
     // ahc_prepare expands the records into a private working copy (merged in place)
     std::vector<int64_t> offs;
     std::vector<int32_t> prob_of;
-    if ((st = ahc_prepare(c, d_stats, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs, prob_of)) != SPKD_OK) return st;
+    if ((st = ahc_prepare(c, d_stats, h_seg_off, n_prob, P->variant, P->kind, P->lambdac, B, n_total, offs, prob_of, plan)) != SPKD_OK) return st;
     int64_t n_max = 0;
     for (int64_t p = 0; p < n_prob; ++p) n_max = std::max<int64_t>(n_max, h_seg_off[p + 1] - h_seg_off[p]);
     if (n_max > AHC_MAX_N) return fail(c, SPKD_EINVAL, "clustering problem larger than 65536 records");
@@ -554,6 +631,28 @@ spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         }
     }
     return st;
+}
+}  // namespace
+
+spkd_status spkd_ahc(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_off, int64_t n_prob,
+                     const spkd_ahc_params* P, int32_t* h_n_merges, int32_t* h_merge_a,
+                     int32_t* h_merge_b, double* h_merge_d, double* h_stat_max, double* h_stat_min) {
+    return ahc_impl(c, d_stats, h_seg_off, n_prob, P, MatrixPlan(), h_n_merges, h_merge_a, h_merge_b, h_merge_d,
+                    h_stat_max, h_stat_min);
+}
+
+spkd_status spkd_ahc_matrix(spkd_ctx* c, const double* d_stats, int64_t n, const spkd_ahc_params* P,
+                            const double* d_matrix, double stat_max_in, double stat_min_in,
+                            int32_t* h_n_merges, int32_t* h_merge_a, int32_t* h_merge_b, double* h_merge_d,
+                            double* h_stat_max, double* h_stat_min) {
+    if (!c || n < 1) return SPKD_EINVAL;
+    if (!d_matrix) return fail(c, SPKD_EINVAL, "ahc_matrix: null matrix");
+    const int64_t seg_off[2] = {0, n};
+    MatrixPlan plan;
+    plan.d_init = d_matrix;
+    plan.init_max = stat_max_in;
+    plan.init_min = stat_min_in;
+    return ahc_impl(c, d_stats, seg_off, 1, P, plan, h_n_merges, h_merge_a, h_merge_b, h_merge_d, h_stat_max, h_stat_min);
 }
 
 // ------------------------------------------------------------------ (3) change detection
@@ -657,7 +756,7 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if (!d_turns || !d_snap || !d_cand || !d_i32a || !d_i32b || !d_d0 || !d_d1 || !d_d2 || !d_d3 || !d_d4 ||
         !d_log || !c->d_counter || !c->d_err)
         return fail(c, SPKD_EHIP, "gw: a device scratch buffer is missing");
-    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 2 * sizeof(unsigned long long), c->stream));   // [0] log entries, [1] determinants
     // A turn is a serial chain of scans.  With few turns a workgroup of four waves shares a
     // turn's matrices (latency); with thousands, ONE WAVE per turn keeps every wave of the
     // chip busy with its own chain (throughput): no wave waits at a barrier for the serial
@@ -674,7 +773,8 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     TIMED(c, SPKD_T_GW, if (nw == 1) SPKD_GW_LAUNCH(1); else if (nw == 2) SPKD_GW_LAUNCH(2); else SPKD_GW_LAUNCH(4));
 #undef SPKD_GW_LAUNCH
     HIPCHK(c, hipGetLastError());
-    unsigned long long cnt = 0;
+    unsigned long long cnt2[2] = {0ull, 0ull};
+    unsigned long long& cnt = cnt2[0];
     HIPCHK(c, hipMemcpyAsync(h_n_win, d_i32a, (size_t)n_turns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_win_maxd, d_d0, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_win_det, d_i32b, (size_t)n_ev * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -682,8 +782,9 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     HIPCHK(c, hipMemcpyAsync(h_det_maxi, d_d2, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_det_d, d_d3, (size_t)n_ev * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_final_start, d_d4, (size_t)n_turns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_counter, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cnt2, c->d_counter, sizeof cnt2, hipMemcpyDeviceToHost, c->stream));
     st = end_call(c);
+    c->last_gw_items = (int64_t)cnt2[1];
     if (h_log_count) *h_log_count = (int64_t)cnt;
     if (h_log && log_cap > 0 && cnt > 0) {
         const size_t ncopy = (size_t)std::min<int64_t>((int64_t)cnt, log_cap);

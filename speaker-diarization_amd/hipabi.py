@@ -18,10 +18,10 @@ REC = 820
 DIM = 39
 
 EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_destroy', 'spkd_last_error', 'spkd_sync',
-           'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h',
-           'spkd_last_kernel_ms', 'spkd_set_stats', 'spkd_pair_terms',
+           'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h', 'spkd_memcpy_d2d',
+           'spkd_last_kernel_ms', 'spkd_last_gw_items', 'spkd_set_stats', 'spkd_pair_terms',
            'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats', 'spkd_mfcc',
-           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_py2_roundtrip',
+           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_ahc_matrix', 'spkd_distance_rows', 'spkd_py2_roundtrip',
            'spkd_labels_from_merges', 'spkd_labels_from_merges_batch', 'spkd_count_flags', 'spkd_gw_lines']
 
 
@@ -112,7 +112,9 @@ def load_library(path=None):
     lib.spkd_free.argtypes = [vp, vp]
     lib.spkd_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.spkd_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.spkd_memcpy_d2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.spkd_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
+    lib.spkd_last_gw_items.argtypes = [vp, P(C.c_int64)]
     lib.spkd_set_stats.argtypes = [vp, vp, i64, vp, vp, vp, i64, i64, vp]
     lib.spkd_pair_terms.argtypes = [vp, vp, vp, vp, i64, C.c_int, vp]
     lib.spkd_distance_matrix.argtypes = [vp, C.c_int, dbl, vp, i64, vp]
@@ -132,6 +134,8 @@ def load_library(path=None):
     lib.spkd_sw_window_count.restype = i64
     lib.spkd_sw.argtypes = [vp, vp, i64, vp, vp, i64, P(CdParams), vp, vp]
     lib.spkd_ahc.argtypes = [vp, vp, vp, i64, P(AhcParams), vp, vp, vp, vp, vp, vp]
+    lib.spkd_ahc_matrix.argtypes = [vp, vp, i64, P(AhcParams), vp, dbl, dbl, vp, vp, vp, vp, vp, vp]
+    lib.spkd_distance_rows.argtypes = [vp, C.c_int, C.c_int, dbl, vp, i64, i64, i64, vp, P(dbl), P(dbl)]
     lib.spkd_py2_roundtrip.argtypes = [vp, i64]
     lib.spkd_py2_roundtrip.restype = None
     lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
@@ -267,6 +271,12 @@ class Context(object):
         self.check(self.lib.spkd_last_kernel_ms(self.h, TIMERS[which], C.byref(ms)))
         return ms.value
 
+    def last_gw_items(self):
+        """39x39 determinants evaluated by the most recent growing-window call."""
+        n = C.c_int64()
+        self.check(self.lib.spkd_last_gw_items(self.h, C.byref(n)))
+        return int(n.value)
+
     # ---- device memory for torch-less hosts
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
@@ -292,6 +302,9 @@ class Context(object):
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self.check(self.lib.spkd_memcpy_h2d(self.h, C.c_void_p(dptr), _ptr(arr), arr.nbytes))
+
+    def copy_d2d(self, d_dst, d_src, nbytes):
+        self.check(self.lib.spkd_memcpy_d2d(self.h, C.c_void_p(d_dst), C.c_void_p(d_src), int(nbytes)))
 
     def d2h(self, arr, dptr):
         assert arr.flags['C_CONTIGUOUS']
@@ -433,5 +446,33 @@ class Context(object):
         smin = np.zeros(npb, dtype=np.float64)
         st = self.lib.spkd_ahc(self.h, C.c_void_p(d_stats), _ptr(seg_off), npb, C.byref(params),
                                _ptr(n_merges), _ptr(ma), _ptr(mb), _ptr(md), _ptr(smax), _ptr(smin))
+        self.check(st, allow=(SPKD_ENONFINITE,))
+        return dict(status=st, n_merges=n_merges, a=ma, b=mb, d=md, stat_max=smax, stat_min=smin)
+
+    def distance_rows(self, variant, kind, lambdac, d_stats, n, row_begin, row_end, d_rows):
+        """Rows [row_begin, row_end) of the initial matrix of one n-record problem -> d_rows
+        (device, (row_end - row_begin) * n doubles); returns (max, min) over the block's finite
+        distances (NaN: none)."""
+        smax, smin = C.c_double(), C.c_double()
+        st = self.lib.spkd_distance_rows(self.h, int(variant), KINDS[kind] if isinstance(kind, str) else int(kind),
+                                         float(lambdac), C.c_void_p(d_stats), int(n), int(row_begin), int(row_end),
+                                         C.c_void_p(d_rows), C.byref(smax), C.byref(smin))
+        self.check(st, allow=(SPKD_ENONFINITE,))
+        if st == SPKD_ENONFINITE:
+            raise ValueError('array must not contain infs or NaNs')
+        return smax.value, smin.value
+
+    def ahc_matrix(self, d_stats, n, params, d_matrix, stat_max_in=float('nan'), stat_min_in=float('nan')):
+        """The merge loop of one n-record problem on a caller-supplied initial matrix."""
+        n = int(n)
+        n_merges = np.zeros(1, dtype=np.int32)
+        ma = np.zeros(n, dtype=np.int32)
+        mb = np.zeros(n, dtype=np.int32)
+        md = np.zeros(n, dtype=np.float64)
+        smax = np.zeros(1, dtype=np.float64)
+        smin = np.zeros(1, dtype=np.float64)
+        st = self.lib.spkd_ahc_matrix(self.h, C.c_void_p(d_stats), n, C.byref(params), C.c_void_p(d_matrix),
+                                      float(stat_max_in), float(stat_min_in), _ptr(n_merges), _ptr(ma), _ptr(mb),
+                                      _ptr(md), _ptr(smax), _ptr(smin))
         self.check(st, allow=(SPKD_ENONFINITE,))
         return dict(status=st, n_merges=n_merges, a=ma, b=mb, d=md, stat_max=smax, stat_min=smin)

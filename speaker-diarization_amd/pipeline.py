@@ -86,6 +86,7 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
         timings.setdefault('gw_stream_ms', []).append(ctx.last_ms('call'))     # uploads + kernel + result copies
         timings['gw_frames'] = int((te - tb).sum())
         timings['gw_windows'] = int(r['n_win'].sum())
+        timings['gw_dets'] = ctx.last_gw_items()
     if r['status'] == hipabi.SPKD_ENONFINITE:
         raise ValueError('array must not contain infs or NaNs')
     off = r['off']
@@ -113,6 +114,47 @@ def change_detect_batch(ctx, d_frames, total_frames, files, rate=125.0, cd=DIA2_
     return out
 
 
+def segment_stats(ctx, d_frames, total_frames, files, segments, rate=125.0, timings=None, fused=None,
+                  scratch_name='segment_stats'):
+    """The statistics record of every segment (get_spk_features + the np.cov inputs,
+    spk-clustering.py:46-52, 88-94) -> (device pointer to n records in segment order,
+    seg_off per file, n, time stamp after the host preparation).  fused: see cluster_batch."""
+    cnt = [len(s) for s in segments]
+    seg_off = np.zeros(len(files) + 1, dtype=np.int64)
+    seg_off[1:] = np.cumsum(cnt)
+    n = int(seg_off[-1])
+    allseg = np.concatenate([np.asarray(s, dtype=np.float64).reshape(-1, 2) for s in segments]) if n else np.zeros((0, 2))
+    owner = np.repeat(np.arange(len(files)), cnt)
+    foff = np.array([f.frame_off for f in files], dtype=np.int64)[owner]
+    fn = np.array([f.n_frames for f in files], dtype=np.int64)[owner]
+    a0 = np.clip((allseg[:, 0] * rate).astype(np.int64), 0, fn)
+    a1 = np.maximum(a0, np.clip((allseg[:, 1] * rate).astype(np.int64), 0, fn))
+    b, e = foff + a0, foff + a1
+    d_stats = ctx.dev_scratch(scratch_name, max(n, 1) * hipabi.REC * 8)
+    _t1 = time.perf_counter()
+    if fused is None:
+        ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
+        redo = np.arange(n)
+    else:
+        same = (fused.begin == b) & (fused.end == e)
+        keep = np.nonzero(same)[0]
+        redo = np.nonzero(~same)[0]
+        ctx.gather_stats(fused.d_buf, fused.n_buf, fused.index[keep], d_stats, n, keep)
+        if len(redo):
+            d_tmp = ctx.dev_scratch(scratch_name + '_redo', len(redo) * hipabi.REC * 8)
+            ctx.set_stats(d_frames, total_frames, b[redo], e[redo], np.arange(len(redo), dtype=np.int32),
+                          len(redo), d_tmp)
+            ctx.gather_stats(d_tmp, len(redo), np.arange(len(redo)), d_stats, n, redo)
+    if timings is not None:
+        if len(redo):
+            timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
+            timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
+        timings['stats_frames'] = int((e[redo] - b[redo]).sum())
+        timings['stats_sets'] = n
+        timings['stats_recomputed'] = int(len(redo))
+    return d_stats, seg_off, n, _t1
+
+
 def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=DIA2_CL, timings=None,
                   want_merges=False, fused=None):
     """segments: per file, array [(start_s, end_s)] as the clustering script parses
@@ -135,39 +177,8 @@ def cluster_batch(ctx, d_frames, total_frames, files, segments, rate=125.0, cl=D
         return out
     _t0 = time.perf_counter()
     cnt = [len(s) for s in segments]
-    seg_off = np.zeros(len(files) + 1, dtype=np.int64)
-    seg_off[1:] = np.cumsum(cnt)
-    n = int(seg_off[-1])
-    allseg = np.concatenate([np.asarray(s, dtype=np.float64).reshape(-1, 2) for s in segments]) if n else np.zeros((0, 2))
-    owner = np.repeat(np.arange(len(files)), cnt)
-    foff = np.array([f.frame_off for f in files], dtype=np.int64)[owner]
-    fn = np.array([f.n_frames for f in files], dtype=np.int64)[owner]
-    a0 = np.clip((allseg[:, 0] * rate).astype(np.int64), 0, fn)
-    a1 = np.maximum(a0, np.clip((allseg[:, 1] * rate).astype(np.int64), 0, fn))
-    b, e = foff + a0, foff + a1
-    d_stats = ctx.dev_scratch('segment_stats', max(n, 1) * hipabi.REC * 8)
-    _t1 = time.perf_counter()
-    if fused is None:
-        ctx.set_stats(d_frames, total_frames, b, e, np.arange(n, dtype=np.int32), n, d_stats)
-        redo = np.arange(n)
-    else:
-        same = (fused.begin == b) & (fused.end == e)
-        keep = np.nonzero(same)[0]
-        redo = np.nonzero(~same)[0]
-        ctx.gather_stats(fused.d_buf, fused.n_buf, fused.index[keep], d_stats, n, keep)
-        if len(redo):
-            d_tmp = ctx.dev_scratch('segment_stats_redo', len(redo) * hipabi.REC * 8)
-            ctx.set_stats(d_frames, total_frames, b[redo], e[redo], np.arange(len(redo), dtype=np.int32),
-                          len(redo), d_tmp)
-            ctx.gather_stats(d_tmp, len(redo), np.arange(len(redo)), d_stats, n, redo)
+    d_stats, seg_off, n, _t1 = segment_stats(ctx, d_frames, total_frames, files, segments, rate, timings, fused)
     _t2 = time.perf_counter()
-    if timings is not None:
-        if len(redo):
-            timings.setdefault('chunk_stats', []).append(ctx.last_ms('chunk_stats'))
-            timings.setdefault('reduce_sets', []).append(ctx.last_ms('reduce_sets'))
-        timings['stats_frames'] = int((e[redo] - b[redo]).sum())
-        timings['stats_sets'] = n
-        timings['stats_recomputed'] = int(len(redo))
     p = hipabi.AhcParams(cl['variant'], hipabi.KINDS[cl['kind']], cl['max_spk'], cl.get('path', 0),
                          cl['lambdac'], cl['threshold'])
     r = ctx.ahc(d_stats, seg_off, p)
