@@ -87,6 +87,11 @@ def parse():
     ap.add_argument('--share-device', action='store_true',
                     help='rehearsal only: every rank uses GPU 0 (needs --backend gloo)')
     ap.add_argument('--dump-rows', default='', help='rank 0 writes the gathered rows of the last step here (.npz)')
+    ap.add_argument('--long-file', action='store_true',
+                    help='BASELINE config 5 instead of the batch: ONE file of --seconds (default 36000) / --speakers '
+                         '(default 8) sharded in time over the ranks (distributed.diarize_long_file: all_gather of the '
+                         'segment records, a row block of the N x N matrix per rank, merge loop replicated); the line '
+                         'carries the per-phase times of the slowest rank')
     return ap.parse_args()
 
 
@@ -209,6 +214,8 @@ def main():
     import torch.distributed as dist
     if world != max(1, args.gpus):
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.long_file:
+        return long_file_main(args, rank, local, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
     if args.share_device:
@@ -501,6 +508,95 @@ def main():
         dist.destroy_process_group()
 
 
+def long_file_main(args, rank, local, world):
+    """One long file over the ranks (BASELINE config 5): a step is the
+    whole file from resident frames to labelled rows on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    if args.share_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    hipabi = importlib.import_module(PKG + '.hipabi')
+    synth_device = importlib.import_module(PKG + '.synth_device')
+    rec = importlib.import_module(PKG + '.recipe')
+    dmod = importlib.import_module(PKG + '.distributed')
+    seconds = args.seconds if args.seconds != 3600.0 else 36000.0
+    speakers = args.speakers if args.speakers != 4 else 8
+    feats, vad, _ = synth_device.make_session_device(424242, seconds, speakers, device=dev)
+    T = int(feats.shape[0])
+    vad_t = [(float(rec.py2_float_str(s / 125.0)), float(rec.py2_float_str(e / 125.0))) for (s, e) in vad]
+    lo, hi = dmod.shard_turns(vad_t, world)[rank]
+    f0 = 0 if lo == 0 else min(T, int(vad_t[lo - 1][1] * 125.0))
+    f1 = T if hi == len(vad_t) else min(T, int(vad_t[hi - 1][1] * 125.0))
+    shard = feats[f0:f1].clone()                      # this rank keeps ITS time shard only
+    del feats
+    torch.cuda.synchronize()
+    ctx = hipabi.Context(local, torch.cuda.current_stream().cuda_stream)
+    grp = dist if world > 1 else None
+
+    def step(tm):
+        return dmod.diarize_long_file(ctx, shard.data_ptr(), f0, f1 - f0, T, vad_t[lo:hi], grp, timings=tm)
+
+    rows0 = step({})
+    for _ in range(max(0, args.warmup - 1)):
+        step({})
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    phases = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tm = {}
+        rows = step(tm)
+        phases.append(tm['long_file_ms'])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if not np.array_equal(rows, rows0):
+        raise SystemExit('bench.py --long-file: a timed step produced different rows')
+    keys = ['change_detection', 'segment_stats', 'gather_records', 'matrix_rows', 'gather_rows',
+            'assemble_and_merge_loop', 'labels', 'total']
+    mine = np.array([[np.mean([p[k] for p in phases]) for k in keys] + [dt]])
+    if world > 1:
+        t = torch.from_numpy(mine).to(dev if args.backend == 'nccl' else 'cpu')
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        every = np.concatenate([e.cpu().numpy() for e in every])
+    else:
+        every = mine
+    dt = float(every[:, -1].max())
+    if rank == 0:
+        hours = (seconds / 3600.0) * args.steps
+        res = {'metric': 'diarized audio throughput, ONE long file sharded in time over the GPUs (CD gw/BIC + CL hi/BIC)',
+               'value': hours / dt, 'unit': 'hours-audio/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+               'dtype': 'f64', 'data': 'synthetic', 'xRT': hours / dt * 3600.0,
+               'config': {'workload': 'one %.0f s / %d-speaker file (BASELINE config 5), %d frames, %d segments; frames '
+                                      'resident in HBM, time-sharded between VAD turns; DIA2 flags'
+                                      % (seconds, speakers, T, phases[-1]['segments']),
+                          'parallelism': 'time shards x%d: all_gather of segment records, matrix row blocks, '
+                                         'merge loop replicated' % world},
+               # per phase: the slowest rank's mean over the steps (ms)
+               'phases_ms_max_over_ranks': {k: round(float(every[:, i].max()), 3) for i, k in enumerate(keys)},
+               'phases_ms_rank0': {k: round(float(every[0, i]), 3) for i, k in enumerate(keys)},
+               'segments': phases[-1]['segments'], 'rows_of_rank0': phases[-1]['rows_of_this_rank'],
+               'note': 'the merge loop is a serial chain replicated on every rank: only change_detection, '
+                       'segment_stats and matrix_rows shrink with the rank count (DESIGN.md par. 6)'}
+        print(json.dumps(res))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def with_uploads(torch, dev, args, frames, total, files, pipeline, ctx, cl, fused, digest0):
     """What the headline leaves out, measured: the same steps with every batch coming from
     PINNED HOST memory.  Two device buffers; the upload of batch k + 1 runs on a copy stream
@@ -618,6 +714,22 @@ def other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, lo
                      'speakers_found': int(rows[0][:, 2].max()) if len(rows[0]) else 0,
                      'xRT': round(secs / (float(np.median(walls[1:])) / 1e3), 0),
                      'k_gw_ms': g('gw'), 'k_matrix_ms': g('matrix'), 'ahc_ms': g('ahc')}
+        if name == 'config2_1h_4spk':
+            # the reference's DEFAULT stand-alone mode on the same file: -m sw -d GLR -w 5.0 -st 0.5
+            # (spk-change-detection.py:436-447): distances of every sliding window of every VAD turn
+            tb = np.array([int(s * 125.0) for (s, e) in f[0].vad], dtype=np.int64)
+            te = np.array([int(e * 125.0) for (s, e) in f[0].vad], dtype=np.int64)
+            p = hipabi.CdParams(hipabi.KINDS['GLR'], 0, 1.3, 0.0, float(np.floor(5.0 * 125.0)),
+                                float(np.floor(0.5 * 125.0)), float(np.floor(125.0 * 0.05)), 125.0)
+            sw_walls = []
+            for it in range(4):
+                t0 = time.perf_counter()
+                _, off, d = ctx.sw(feats.data_ptr(), int(feats.shape[0]), tb, te, p)
+                sw_walls.append(1e3 * (time.perf_counter() - t0))
+            out['sw_glr_1h'] = {'ms': round(float(np.median(sw_walls[1:])), 3), 'windows': int(len(d)),
+                                'kernels_ms': round(ctx.last_ms('sw'), 3),
+                                'note': 'sliding-window GLR distances (-w 5.0 -st 0.5) of every VAD turn of the 1 h file: '
+                                        'two statistics records per window from the frames + the pair kernels'}
         del feats
     return out
 

@@ -1,5 +1,4 @@
-// Change-detection kernels: growing window (dist_gw, spk-change-detection.py:180-288)
-// and sliding window (dist_sw, spk-change-detection.py:291-357, distances only).
+// Change-detection kernels: growing window (dist_gw, spk-change-detection.py:180-288).
 //
 // Growing window: one workgroup per VAD turn.  The statistics of every frame range
 // the scan needs are differences of running moment sums P(t) = sum of [x;1][x;1]^T
@@ -14,8 +13,9 @@
 // The growing-window decision chain (a float state machine with int() truncation,
 // SURVEY.md A-1) runs on the device with the exact operation order of the reference.
 //
-// Sliding window (not on the DIA2 path): prefix snapshots every SNAP_G frames and
-// the row-per-lane layout.
+// Sliding window (dist_sw, spk-change-detection.py:291-357): no kernel of its own -- every
+// window is a pair distance between two frame sets, computed by the statistics and
+// clustering kernels (spkd_sw in spkd_hip.hip).
 #pragma once
 #include <type_traits>
 #include "spkd_device.hpp"
@@ -25,15 +25,11 @@
 
 namespace spkd {
 
-constexpr int SNAP_G = 16;
-constexpr int CD_TILE = 64;
 constexpr double NEG_MAXINT_M1 = -9223372036854775808.0;   // -sys.maxint - 1
-constexpr int QUSE = QS * DA * QL;                         // row-carrying entries of a quad record
 
 struct TurnDesc {
     int64_t begin;       // first frame of the turn in the frame array
     int64_t len;         // frames
-    int64_t snap_off;    // first snapshot record of this turn
     int64_t cand_off;    // first candidate slot
     int64_t cand_cap;    // candidate slots owned by this turn
     int64_t ev_off;      // first event slot
@@ -41,130 +37,10 @@ struct TurnDesc {
     int64_t id;          // caller's turn index (blocks are launched longest turn first)
 };
 
-// e in [0, QUSE) -> quad-record index and the (row, column) it holds
-__device__ __forceinline__ void quse_decode(int e, int& idx, int& i, int& j) {
-    const int s = e / (DA * QL), rem = e - s * (DA * QL);
-    j = rem / QL;
-    const int t = rem - j * QL;
-    i = QL * s + t;
-    idx = (s * DA + j) * 16 + t;
-}
-
-// Phase 1: snapshots snap[k] = moments of turn frames [0, G*k), k = 0 .. len / G.
-// Thread (row i, column group g) owns the entries (i, g + 6 m), m = 0..6: per frame
-// it reads x_i once and one x_j per entry from the LDS tile (already converted to
-// double when staged), i.e. 8 LDS reads + 7 FMAs per frame.  Sums are in frame order.
-constexpr int P1_GROUPS = 6;
-constexpr int P1_COLS = (DA + P1_GROUPS - 1) / P1_GROUPS;     // 7
-
-template <int TPB>
-__device__ __forceinline__ void build_prefix(const float* __restrict__ fr, long long n,
-                                             double* __restrict__ snap, double* xs) {
-    static_assert(TPB >= D * P1_GROUPS, "phase 1 needs 234 threads");
-    const int tid = threadIdx.x;
-    const bool on = tid < D * P1_GROUPS;
-    const int i = on ? tid % D : 0, g = on ? tid / D : 0;
-    const int rbase = (i / QL) * DA * 16 + (i % QL);          // + j * 16
-    double acc[P1_COLS];
-#pragma unroll
-    for (int m = 0; m < P1_COLS; ++m) {
-        acc[m] = 0.0;
-        const int j = g + P1_GROUPS * m;
-        if (on && j < DA) snap[rbase + j * 16] = 0.0;
-    }
-    if (tid == 0) snap[QREC_COUNT_AT] = 0.0;
-    for (long long t0 = 0; t0 < n; t0 += CD_TILE) {
-        const int tl = (int)((n - t0) < CD_TILE ? (n - t0) : CD_TILE);
-        const float* src = fr + t0 * D;
-        for (int idx = tid; idx < tl * D; idx += TPB) {
-            int f = idx / D, c = idx - f * D;
-            xs[f * DA + c] = (double)src[idx];
-        }
-        if (tid < tl) xs[tid * DA + D] = 1.0;
-        __syncthreads();
-        for (int f = 0; f < tl; ++f) {
-            const double xi = xs[f * DA + i];
-#pragma unroll
-            for (int m = 0; m < P1_COLS; ++m) {
-                const int j = g + P1_GROUPS * m;
-                acc[m] = fma(xi, xs[f * DA + (j < DA ? j : 0)], acc[m]);
-            }
-            const long long t = t0 + f + 1;
-            if ((t % SNAP_G) == 0) {
-                double* dst = snap + (t / SNAP_G) * QREC;
-#pragma unroll
-                for (int m = 0; m < P1_COLS; ++m) {
-                    const int j = g + P1_GROUPS * m;
-                    if (on && j < DA) dst[rbase + j * 16] = acc[m];
-                }
-                if (tid == 0) dst[QREC_COUNT_AT] = (double)t;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// Row-per-lane (single matrix) prefix rows from the snapshots (sliding window).
-__device__ __forceinline__ void single_prefix_rows(double (&q)[DA], const double* __restrict__ snap,
-                                                   const float* __restrict__ fr, long long t) {
-    const long long k = t / SNAP_G;
-    single_rows_from_qr(snap + k * QREC, q);
-    const int lane = lane_id();
-    for (long long f = k * SNAP_G; f < t; ++f) {
-        const float x = (lane < D) ? fr[f * D + lane] : 0.0f;
-        const double xi = (double)x;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            const double xc = readlane_d(xi, c);
-            q[c] = fma(xi, xc, q[c]);
-        }
-        q[D] += xi;
-    }
-}
-
-__device__ __forceinline__ void single_rows_from_lds(const double* lds, double (&q)[DA]) {
-    int i = lane_id();
-    i = i >= D ? D - 1 : i;
-    const int base = (i / QL) * DA * 16 + (i % QL);
-#pragma unroll
-    for (int j = 0; j < DA; ++j) q[j] = lds[base + j * 16];
-}
-
 struct BestD {
     double d;
     long long k;
 };
-
-// first-index arg max over candidates accepted by "d > maxd and d != inf"
-// starting from `floor` (exclusive); k = -1 when none.
-template <int NWAVES>
-__device__ __forceinline__ BestD block_argmax(const double* __restrict__ vals, long long count,
-                                              double floor_excl, BestD* red) {
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    BestD b;
-    b.d = floor_excl; b.k = -1;
-    for (long long k = tid; k < count; k += NWAVES * WAVE) {
-        const double d = vals[k];
-        if (d > b.d && d != __builtin_huge_val()) { b.d = d; b.k = k; }   // NaN fails d > b.d
-    }
-#pragma unroll
-    for (int s = 1; s < WAVE; s <<= 1) {
-        const double d2 = __shfl_xor(b.d, s);
-        const long long k2 = __shfl_xor(b.k, s);
-        const bool take = (k2 >= 0) && (b.k < 0 || d2 > b.d || (d2 == b.d && k2 < b.k));
-        if (take) { b.d = d2; b.k = k2; }
-    }
-    if (lane == 0) red[wave] = b;
-    __syncthreads();
-    BestD r = red[0];
-    for (int w = 1; w < NWAVES; ++w) {
-        const BestD o = red[w];
-        const bool take = (o.k >= 0) && (r.k < 0 || o.d > r.d || (o.d == r.d && o.k < r.k));
-        if (take) r = o;
-    }
-    __syncthreads();
-    return r;
-}
 
 __device__ __forceinline__ void log_cand(spkd_cand_log* log, long long cap, unsigned long long* count,
                                          int turn, int coarse, long long seq, double start, double i,
@@ -1187,101 +1063,6 @@ __global__ __launch_bounds__(Gw<NW>::TPB, 2) void k_gw(
     }
     if (lane == 0) atomicAdd(&g_gw_prof[6], prof_passes);
 #endif
-}
-
-// ---------------------------------------------------------------------------
-// Sliding window: every window is independent; one wave per window, row-per-lane
-// layout (this mode is not on the DIA2 path; the quad layout is used where the
-// time goes).
-constexpr int SW_WAVES = 4;
-constexpr int SW_TPB = SW_WAVES * WAVE;
-
-__global__ __launch_bounds__(SW_TPB) void k_sw(
-        const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
-        double* __restrict__ snap_all, double* __restrict__ d_out, int* err) {
-    __shared__ double xs[CD_TILE * DA];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int turn = blockIdx.x;
-    const TurnDesc T = turns[turn];
-    const long long n = T.len;
-    const float* fr = frames + T.begin * D;
-    double* snap = snap_all + T.snap_off * QREC;
-    build_prefix<SW_TPB>(fr, n, snap, xs);
-    __syncthreads();
-    const int kind = P.kind;
-    const double winsize = P.winsize, winstep = P.winstep;
-    long long W = 0;
-    for (double s = 0; s + 2 * winsize <= (double)n; s += winstep) ++W;
-    const long long wsz = (long long)winsize;
-    for (long long w = wave; w < W; w += SW_WAVES) {
-        const long long a = (long long)((double)w * winstep);
-        const long long m = a + wsz, e = a + 2 * wsz;
-        double qa[DA], qm[DA], qe[DA], a_[DA];
-        single_prefix_rows(qa, snap, fr, a);
-        single_prefix_rows(qm, snap, fr, m);
-        single_prefix_rows(qe, snap, fr, e);
-        const double n1 = (double)wsz, n2 = (double)wsz, N = n1 + n2;
-        double r[3] = {0.0, 0.0, 0.0};
-        double kl = 0.0;
-        if (kind == SPKD_KL2) {
-            double ds[2], dp[2], mu[2];
-#pragma unroll 1
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int j = 0; j < DA; ++j) a_[j] = t ? (qe[j] - qm[j]) : (qm[j] - qa[j]);
-                const double mean_i = a_[D] / n1;
-                cov_rows(a_, n1);
-                kl2_lane_terms(a_, mean_i, ds[t], dp[t], mu[t]);
-            }
-            kl = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
-        } else {
-#pragma unroll 1
-            for (int t = 0; t < 3; ++t) {
-                auto form = [&](double (&q)[DA]) {
-                    if (t == 0) {
-#pragma unroll
-                        for (int j = 0; j < DA; ++j) q[j] = qm[j] - qa[j];
-                        cov_rows(q, n1);
-                    } else if (t == 1) {
-#pragma unroll
-                        for (int j = 0; j < DA; ++j) q[j] = qe[j] - qm[j];
-                        cov_rows(q, n2);
-                    } else if (kind == SPKD_BIC) {
-#pragma unroll
-                        for (int j = 0; j < DA; ++j) q[j] = qe[j] - qa[j];
-                        cov_rows(q, N);
-                    } else {
-                        const double al1 = (n1 / N) / (n1 - 1.0), al2 = (n2 / N) / (n2 - 1.0);
-                        const double be1 = al1 / n1, be2 = al2 / n2;
-                        const double s1i = qm[D] - qa[D];
-                        const double s2i = qe[D] - qm[D];
-#pragma unroll
-                        for (int j = 0; j < D; ++j) {
-                            const double q1 = qm[j] - qa[j];
-                            const double q2 = qe[j] - qm[j];
-                            const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
-                            double v = fma(al2, q2, al1 * q1);
-                            v = fma(-(be1 * s1i), s1j, v);
-                            q[j] = fma(-(be2 * s2i), s2j, v);
-                        }
-                    }
-                };
-                r[t] = logdet_formed(a_, err, form);
-            }
-        }
-        if (lane == 0) {
-            double d;
-            if (kind == SPKD_BIC) {
-                d = 0.5 * N * r[2] - 0.5 * n1 * r[0] - 0.5 * n2 * r[1];
-                d -= P.lambdac * 0.5 * PEN_UNIT * log(N);
-            } else if (kind == SPKD_GLR) {
-                d = -(N / 2.0) * ((n1 / N) * r[0] + (n2 / N) * r[1] - r[2]);
-            } else {
-                d = kl;
-            }
-            d_out[T.ev_off + w] = d;
-        }
-    }
 }
 
 }  // namespace spkd

@@ -257,14 +257,14 @@ spkd_status spkd_last_kernel_ms(spkd_ctx* c, int which, float* ms) {
 }
 
 // ------------------------------------------------------------------ (1) stats
-spkd_status spkd_set_stats(spkd_ctx* c, const float* d_frames, int64_t n_frames,
-                           const int64_t* h_begin, const int64_t* h_end, const int32_t* h_set,
-                           int64_t n_ranges, int64_t n_sets, double* d_stats) {
-    if (!c || !d_stats || n_sets < 0 || n_ranges < 0) return SPKD_EINVAL;
-    if (n_sets == 0) return SPKD_OK;
-    if (n_ranges > 0 && (!h_begin || !h_end || !h_set || !d_frames)) return fail(c, SPKD_EINVAL, "null range arrays");
-    std::vector<Chunk> chunks;
-    std::vector<int64_t> set_off((size_t)n_sets + 1, 0);
+namespace {
+// the launches of spkd_set_stats, without the call bracket (spkd_sw uses them too)
+spkd_status set_stats_launch(spkd_ctx* c, const float* d_frames, int64_t n_frames,
+                             const int64_t* h_begin, const int64_t* h_end, const int32_t* h_set,
+                             int64_t n_ranges, int64_t n_sets, double* d_stats,
+                             std::vector<Chunk>& chunks, std::vector<int64_t>& set_off) {   // both must outlive the stream work
+    chunks.clear();
+    set_off.assign((size_t)n_sets + 1, 0);
     int32_t prev = 0;
     for (int64_t r = 0; r < n_ranges; ++r) {
         const int64_t b = h_begin[r], e = h_end[r];
@@ -282,8 +282,7 @@ spkd_status spkd_set_stats(spkd_ctx* c, const float* d_frames, int64_t n_frames,
         }
     }
     for (int64_t s = 0; s < n_sets; ++s) set_off[(size_t)s + 1] += set_off[(size_t)s];
-    spkd_status st = begin_call(c);
-    if (st != SPKD_OK) return st;
+    spkd_status st;
     Chunk* d_chunks = nullptr;
     int64_t* d_setoff = nullptr;
     void* d_partial = nullptr;
@@ -298,6 +297,24 @@ spkd_status spkd_set_stats(spkd_ctx* c, const float* d_frames, int64_t n_frames,
           hipLaunchKernelGGL(k_reduce_sets, dim3((unsigned)n_sets), dim3(STATS_TPB), 0, c->stream,
                              (const double*)d_partial, d_setoff, d_stats));
     HIPCHK(c, hipGetLastError());
+    return SPKD_OK;
+}
+}  // namespace
+
+spkd_status spkd_set_stats(spkd_ctx* c, const float* d_frames, int64_t n_frames,
+                           const int64_t* h_begin, const int64_t* h_end, const int32_t* h_set,
+                           int64_t n_ranges, int64_t n_sets, double* d_stats) {
+    if (!c || !d_stats || n_sets < 0 || n_ranges < 0) return SPKD_EINVAL;
+    if (n_sets == 0) return SPKD_OK;
+    if (n_ranges > 0 && (!h_begin || !h_end || !h_set || !d_frames)) return fail(c, SPKD_EINVAL, "null range arrays");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    std::vector<Chunk> chunks;
+    std::vector<int64_t> set_off;
+    if ((st = set_stats_launch(c, d_frames, n_frames, h_begin, h_end, h_set, n_ranges, n_sets, d_stats, chunks, set_off)) != SPKD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return st;
+    }
     return end_call(c);
 }
 
@@ -682,8 +699,7 @@ int64_t spkd_sw_window_count(int64_t turn_len, double winsize, double winstep) {
 namespace {
 spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const int64_t* he, int64_t n_turns,
                         const spkd_cd_params* P, const int64_t* h_off, bool gw, std::vector<TurnDesc>& turns,
-                        int64_t& n_snap, int64_t& n_cand) {
-    n_snap = 0;
+                        int64_t& n_cand) {
     n_cand = 0;
     turns.resize((size_t)n_turns);
     for (int64_t t = 0; t < n_turns; ++t) {
@@ -691,8 +707,6 @@ spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const 
         TurnDesc& T = turns[(size_t)t];
         T.begin = hb[t];
         T.len = he[t] - hb[t];
-        T.snap_off = n_snap;
-        n_snap += T.len / SNAP_G + 1;
         T.cand_off = n_cand;
         T.cand_cap = gw ? (int64_t)((double)T.len / (P->rate / 10)) + (int64_t)(2 * (P->rate / 10)) + 16 : 0;
         n_cand += T.cand_cap;
@@ -728,8 +742,8 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if (log_cap < 0 || (log_cap > 0 && !h_log)) return fail(c, SPKD_EINVAL, "gw: log capacity without a log buffer");
     if (!c->gw_lds_ok) return fail(c, SPKD_EHIP, "gw: the kernel's dynamic LDS size was not admitted on this device");
     std::vector<TurnDesc> turns;
-    int64_t n_snap, n_cand;
-    spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_ev_off, true, turns, n_snap, n_cand);
+    int64_t n_cand;
+    spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_ev_off, true, turns, n_cand);
     if (st != SPKD_OK) return st;
     for (int64_t t = 0; check_capacity && t < n_turns; ++t)
         if (turns[(size_t)t].ev_cap < spkd_gw_event_capacity_p(turns[(size_t)t].len, P))
@@ -741,7 +755,6 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
          *d_d2 = nullptr, *d_d3 = nullptr, *d_d4 = nullptr, *d_log = nullptr;
     if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
     // one packed record (running moment sums at the split point) per candidate slot
-    (void)n_snap;
     if ((st = scratch(c, S_SNAP, (size_t)n_cand * REC * sizeof(double), &d_snap)) != SPKD_OK) return st;
     if ((st = scratch(c, S_CAND, (size_t)n_cand * 4 * sizeof(double), &d_cand)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_I32A, (size_t)n_turns * sizeof(int32_t), &d_i32a)) != SPKD_OK) return st;
@@ -862,6 +875,23 @@ spkd_status spkd_gather_stats(spkd_ctx* c, const double* d_src, int64_t n_src, c
     return end_call(c);       // (idx must outlive the copy: end_call waits for the stream)
 }
 
+namespace {
+// D[0][1] of every 2-record problem of a batch of matrices (4 doubles each) -> out[p]
+__global__ __launch_bounds__(256) void k_take_pair_distance(const double* __restrict__ mat, int64_t n, double* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < n) out[p] = mat[4 * p + 1];
+}
+}  // namespace
+
+// Sliding window (dist_sw, spk-change-detection.py:304-312): window w of a turn compares the
+// frames [a, a + size) with [a + size, a + 2 size), a = int(w * step).  Every window is a pair
+// distance between two frame sets, which is what the clustering kernels compute: the two
+// statistics records of every window come from the frames (k_chunk_stats / k_reduce_sets: a
+// window re-reads 2 size / step times the frames of its step, from L2 -- 9 M frame reads for
+// a 1 h turn at the default 5 s / 0.5 s, under a millisecond), their log dets / KL2 vectors
+// from k_cluster_prep (four records per wave) and the pooled (BIC) or within (GLR) term from
+// k_matrix, every window a two-record "problem": the quad elimination and its pivoting
+// fallback serve this mode too, no sliding-window kernel of its own.
 spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
                     const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_d_off,
                     double* h_d) {
@@ -870,26 +900,54 @@ spkd_status spkd_sw(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     if (!d_frames || !hb || !he || !h_d_off || !h_d) return fail(c, SPKD_EINVAL, "null argument");
     if (P->kind < 0 || P->kind > 2) return fail(c, SPKD_EINVAL, "bad kind");
     if (!(P->winsize >= 1.0) || !(P->winstep >= 1.0)) return fail(c, SPKD_EINVAL, "sw: window and step must be >= 1 frame");
-    std::vector<TurnDesc> turns;
-    int64_t n_snap, n_cand;
-    spkd_status st = build_turns(c, n_frames, hb, he, n_turns, P, h_d_off, false, turns, n_snap, n_cand);
-    if (st != SPKD_OK) return st;
-    for (int64_t t = 0; t < n_turns; ++t)
-        if (turns[(size_t)t].ev_cap != spkd_sw_window_count(turns[(size_t)t].len, P->winsize, P->winstep))
-            return fail(c, SPKD_EINVAL, "sw: offsets do not match spkd_sw_window_count");
-    if ((st = begin_call(c)) != SPKD_OK) return st;
     const int64_t n_d = h_d_off[n_turns];
-    TurnDesc* d_turns = nullptr;
-    void *d_snap, *d_out;
-    if ((st = upload(c, S_TURNS, turns, &d_turns)) != SPKD_OK) return st;
-    if ((st = scratch(c, S_SNAP, (size_t)n_snap * QREC * sizeof(double), &d_snap)) != SPKD_OK) return st;
+    std::vector<int64_t> rb, re;
+    std::vector<int32_t> rs;
+    rb.reserve((size_t)(2 * n_d)); re.reserve((size_t)(2 * n_d)); rs.reserve((size_t)(2 * n_d));
+    const int64_t wsz = (int64_t)P->winsize;
+    for (int64_t t = 0; t < n_turns; ++t) {
+        if (hb[t] < 0 || he[t] < hb[t] || he[t] > n_frames) return fail(c, SPKD_EINVAL, "bad turn range");
+        const int64_t len = he[t] - hb[t];
+        const int64_t W = spkd_sw_window_count(len, P->winsize, P->winstep);
+        if (h_d_off[t + 1] - h_d_off[t] != W) return fail(c, SPKD_EINVAL, "sw: offsets do not match spkd_sw_window_count");
+        for (int64_t w = 0; w < W; ++w) {
+            const int64_t a = hb[t] + (int64_t)((double)w * P->winstep);
+            const int32_t s0 = (int32_t)(2 * (h_d_off[t] + w));
+            rb.push_back(a); re.push_back(a + wsz); rs.push_back(s0);
+            rb.push_back(a + wsz); re.push_back(a + 2 * wsz); rs.push_back(s0 + 1);
+        }
+    }
+    if (n_d == 0) return SPKD_OK;
+    if (2 * n_d > 0x7fffffffLL) return fail(c, SPKD_EINVAL, "sw: too many windows in one call");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    void *d_rec = nullptr, *d_out = nullptr;
+    if ((st = scratch(c, S_SNAP, (size_t)(2 * n_d) * REC * sizeof(double), &d_rec)) != SPKD_OK) return st;
     if ((st = scratch(c, S_EV_D0, (size_t)n_d * sizeof(double), &d_out)) != SPKD_OK) return st;
-    TIMED(c, SPKD_T_SW,
-          hipLaunchKernelGGL(k_sw, dim3((unsigned)n_turns), dim3(SW_TPB), 0, c->stream,
-                             d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_out, c->d_err));
+    std::vector<Chunk> chunks;
+    std::vector<int64_t> set_off;
+    (void)hipEventRecord(c->ka[SPKD_T_SW], c->stream);
+    if ((st = set_stats_launch(c, d_frames, n_frames, rb.data(), re.data(), rs.data(), 2 * n_d, 2 * n_d, (double*)d_rec,
+                               chunks, set_off)) != SPKD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return st;
+    }
+    std::vector<int64_t> seg_off((size_t)n_d + 1);
+    for (int64_t w = 0; w <= n_d; ++w) seg_off[(size_t)w] = 2 * w;
+    AhcBuffers B;
+    int64_t n_total = 0;
+    std::vector<int64_t> offs;
+    std::vector<int32_t> prob_of;
+    if ((st = ahc_prepare(c, (const double*)d_rec, seg_off.data(), n_d, 1, P->kind, P->lambdac, B, n_total, offs, prob_of)) != SPKD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return st;
+    }
+    hipLaunchKernelGGL(k_take_pair_distance, dim3((unsigned)((n_d + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double*)B.mat, n_d, (double*)d_out);
+    (void)hipEventRecord(c->kb[SPKD_T_SW], c->stream);
+    c->kused[SPKD_T_SW] = true;
     HIPCHK(c, hipGetLastError());
-    if (n_d > 0)
-        HIPCHK(c, hipMemcpyAsync(h_d, d_out, (size_t)n_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_d, d_out, (size_t)n_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return end_call(c);
 }
 
