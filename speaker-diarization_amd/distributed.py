@@ -252,7 +252,9 @@ def diarize_long_file(ctx, d_shard, shard_frame0, shard_frames, file_frames, vad
         d_up, smax, smin = d_rows, bmax, bmin
     t5 = clock()
     # ---- the full initial matrix in the form the merge loop expects, then the merge loop
-    if keep2 is not None:                                  # RCCL: assemble on the device
+    if not multi:
+        d_M = d_up                                         # one rank: its "block" is the whole matrix, mirror included
+    elif keep2 is not None:                                # RCCL: assemble on the device
         U = keep2
         if variant == 1:
             up = torch.triu(U, 1)
