@@ -159,9 +159,11 @@ typedef struct {         /* one logged candidate evaluation */
 } spkd_cand_log;
 
 /* Growing-window detector, dist_gw (spk-change-detection.py:180-288), all turns
- * of one feature array in one launch, one workgroup per turn.
+ * of one feature array in one launch, one workgroup (few turns) or one wave (thousands of
+ * turns) per turn -- the results are bit-identical.
  * Per turn t the events land at [h_ev_off[t], h_ev_off[t+1]) of the h_win_ and
- * h_det_ arrays; capacity per turn must be >= spkd_gw_event_capacity_p(len, params).
+ * h_det_ arrays; spkd_gw checks capacity per turn >= spkd_gw_event_capacity_p(len, params)
+ * (a first guess, see below: SPKD_EOVERFLOW asks for more).
  * winstep < 1 frame is rejected (the reference's loop does not terminate there).
  *   h_n_win[t]           number of coarse scans (outer iterations)
  *   h_win_maxd[...]      best coarse distance of each scan (NaN: none accepted)
@@ -174,10 +176,17 @@ typedef struct {         /* one logged candidate evaluation */
  * moment sums per candidate slot, about turn_len / (rate / 10) slots per turn (0.52 KB
  * per frame).
  */
+/* Event capacity per turn: a FIRST GUESS, not a bound.  Both count the scans of a window
+ * end that only moves forward (turn_len / step + 8; spkd_gw_event_capacity assumes winstep >=
+ * 0.2 * rate, i.e. -st >= 0.2 s, spkd_gw_event_capacity_p covers every winstep: below that
+ * the window grows by winstep frames per negative scan).  After every detection the
+ * reference resets the window end to start + 2 * winsize (spk-change-detection.py:264-266)
+ * and the window regrows over frames already scanned, so a change point found early in a
+ * long-grown window can make a turn need MORE scans.  Such a call returns SPKD_EOVERFLOW
+ * (nothing is written out of bounds, no result is valid); the caller repeats it with larger
+ * capacities -- any capacity >= the guess is accepted (the Python host doubles until it
+ * fits).  -1 for parameters spkd_gw rejects. */
 int64_t spkd_gw_event_capacity(int64_t turn_len, double rate);
-/* the bound for any window step (spkd_gw_event_capacity assumes winstep >= 0.2 * rate,
- * i.e. -st >= 0.2 s; below that the window grows by winstep frames per negative scan
- * and a turn needs up to turn_len / winstep scans); -1 for parameters spkd_gw rejects */
 int64_t spkd_gw_event_capacity_p(int64_t turn_len, const spkd_cd_params *params);
 spkd_status spkd_gw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
                     const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
@@ -188,9 +197,9 @@ spkd_status spkd_gw(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
                     spkd_cand_log *h_log, int64_t log_cap, int64_t *h_log_count);
 
 /* Same as spkd_gw; with check_capacity = 0 the per-turn capacity implied by
- * h_ev_off may be smaller than spkd_gw_event_capacity() -- a turn that needs more
+ * h_ev_off may also be smaller than spkd_gw_event_capacity_p() -- a turn that needs more
  * makes the call return SPKD_EOVERFLOW (nothing is written out of bounds) and the
- * caller repeats it with the guaranteed capacity. */
+ * caller repeats it with more. */
 spkd_status spkd_gw_ex(spkd_ctx *ctx, const float *d_frames, int64_t n_frames,
                        const int64_t *h_turn_begin, const int64_t *h_turn_end, int64_t n_turns,
                        const spkd_cd_params *params, const int64_t *h_ev_off, int check_capacity,

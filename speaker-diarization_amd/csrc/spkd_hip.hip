@@ -673,10 +673,11 @@ spkd_status spkd_ahc_matrix(spkd_ctx* c, const double* d_stats, int64_t n, const
 }
 
 // ------------------------------------------------------------------ (3) change detection
+// A first guess, not a bound (include/spkd.h): scans of a window end that only moves forward.
 int64_t spkd_gw_event_capacity(int64_t turn_len, double rate) {
     if (turn_len < 0 || !(rate >= 10.0)) return -1;
-    // every outer iteration either advances start by >= 0.4*rate or grows end by >= 0.5*rate
-    // (true while winstep >= 0.2*rate; spkd_gw_event_capacity_p covers every winstep)
+    // an outer iteration that detects advances `start` by >= 0.4*rate, one that does not grows
+    // `end` by >= 0.5*rate (while winstep >= 0.2*rate; spkd_gw_event_capacity_p covers every winstep)
     return (int64_t)((double)turn_len / (0.2 * rate)) + 8;
 }
 
@@ -684,7 +685,10 @@ int64_t spkd_gw_event_capacity_p(int64_t turn_len, const spkd_cd_params* P) {
     if (turn_len < 0 || !P || !(P->rate >= 10.0) || !(P->winstep >= 1.0)) return -1;
     // an outer iteration that detects advances `start` by maxi >= minfeas - istep = 0.4*rate;
     // one that does not grows `end` by ws, and ws is clamped to winstep from the second
-    // growth of an epoch on (CD:273-284): at least min(0.5*rate, winstep) frames
+    // growth of an epoch on (CD:273-284): at least min(0.5*rate, winstep) frames.  What this
+    // leaves out: a detection resets `end` to start + 2*winsize (CD:264-266), the next epoch
+    // regrows over frames the last one had already covered -- turns that re-scan a lot need
+    // more, are told SPKD_EOVERFLOW by the kernel, and are repeated with more by the caller.
     const double step = std::min(0.2 * P->rate, std::min(0.5 * P->rate, P->winstep));
     return (int64_t)((double)turn_len / step) + 8;
 }
@@ -960,15 +964,21 @@ spkd_status spkd_mfcc(spkd_ctx* c, const int16_t* d_pcm, int64_t n_samples, cons
     if (n_samples < 0 || !h_melfb || !h_dct || !h_mean || !h_scale || !h_transform)
         return fail(c, SPKD_EINVAL, "mfcc: null argument");
     if (P->window_width != MF_WIN || P->n_fft != MF_NFFT || P->n_mel != MF_MEL || P->n_cep != MF_CEP ||
-        P->frame_rate <= 0 || P->sample_rate % P->frame_rate != 0)
+        P->frame_rate <= 0 || P->sample_rate <= 0 || P->sample_rate % P->frame_rate != 0)
         return fail(c, SPKD_EINVAL, "mfcc: this build does 400-sample windows, a 512-point transform, 21 mel bins, 12 cepstra");
     if (P->cms_left < 0 || P->cms_right < 0 || P->cms_left + P->cms_right > 1024 || P->delta_width[0] < 1 ||
         P->delta_width[0] > 2 || P->delta_width[1] < 1 || P->delta_width[1] > 2 || !(P->delta_norm[0] > 0.f) ||
         !(P->delta_norm[1] > 0.f))
         return fail(c, SPKD_EINVAL, "mfcc: unsupported mean-subtraction window or delta parameters");
     const int hop = P->sample_rate / P->frame_rate;
+    if (hop < 1) return fail(c, SPKD_EINVAL, "mfcc: frame rate above the sample rate");
+    // everything that can be refused is refused BEFORE the first launch: an early return behind
+    // one would leave the stream with work that references host memory on its way out
+    const int span = MP_FR + 2 * MP_HALO;
+    const size_t lds = (size_t)((span + P->cms_left + P->cms_right) * MF_STATIC + 2 * span * MF_STATIC +
+                                MP_FR * MF_DIM + MF_DIM * MF_DIM) * sizeof(float);
+    if (lds > 60 * 1024) return fail(c, SPKD_EINVAL, "mfcc: mean-subtraction window too wide for the LDS tile");
     const int64_t T = n_samples / hop;
-    *h_n_frames = T;
     if (T == 0) return SPKD_OK;
     if (!d_pcm || !d_features) return fail(c, SPKD_EINVAL, "mfcc: null device buffer");
     spkd_status st = begin_call(c);
@@ -982,8 +992,11 @@ spkd_status spkd_mfcc(spkd_ctx* c, const int16_t* d_pcm, int64_t n_samples, cons
     tab.insert(tab.end(), h_transform, h_transform + MF_DIM * MF_DIM);
     float* d_tab = nullptr;
     void* d_static = nullptr;
-    if ((st = upload(c, S_MFCC_TAB, tab, &d_tab)) != SPKD_OK) return st;
-    if ((st = scratch(c, S_MFCC_STATIC, (size_t)T * MF_STATIC * sizeof(float), &d_static)) != SPKD_OK) return st;
+    if ((st = upload(c, S_MFCC_TAB, tab, &d_tab)) != SPKD_OK ||
+        (st = scratch(c, S_MFCC_STATIC, (size_t)T * MF_STATIC * sizeof(float), &d_static)) != SPKD_OK) {
+        (void)hipStreamSynchronize(c->stream);       // (the upload of `tab` may be in flight)
+        return st;
+    }
     const float* d_fb = d_tab;
     const float* d_dct = d_fb + MF_MEL * MF_BINS;
     const float* d_mean = d_dct + MF_CEP * MF_MEL;
@@ -991,14 +1004,13 @@ spkd_status spkd_mfcc(spkd_ctx* c, const int16_t* d_pcm, int64_t n_samples, cons
     const float* d_tr = d_scale + MF_DIM;
     hipLaunchKernelGGL(k_mfcc_static, dim3((unsigned)((T + MF_FR - 1) / MF_FR)), dim3(MF_TPB), 0, c->stream,
                        d_pcm, (long long)n_samples, (long long)T, hop, P->pre_emph, d_fb, d_dct, (float*)d_static);
-    const int span = MP_FR + 2 * MP_HALO;
-    const size_t lds = (size_t)((span + P->cms_left + P->cms_right) * MF_STATIC + 2 * span * MF_STATIC +
-                                MP_FR * MF_DIM + MF_DIM * MF_DIM) * sizeof(float);
-    if (lds > 60 * 1024) return fail(c, SPKD_EINVAL, "mfcc: mean-subtraction window too wide for the LDS tile");
     hipLaunchKernelGGL(k_mfcc_post, dim3((unsigned)((T + MP_FR - 1) / MP_FR)), dim3(MF_TPB), lds, c->stream,
                        (const float*)d_static, (long long)T, P->cms_left, P->cms_right, P->delta_width[0],
                        P->delta_norm[0], P->delta_width[1], P->delta_norm[1], d_mean, d_scale, d_tr, d_features);
-    HIPCHK(c, hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        return fail(c, SPKD_EHIP, "mfcc: kernel launch failed");
+    }
     return end_call(c);        // (tab must outlive the upload: end_call waits for the stream)
 }
 

@@ -4,6 +4,11 @@ Returns the parameters of the 39-dimensional MFCC chain the reference ships:
 
     audiofile -> fft (magnitude) -> mel -> dct(12) + power -> merge(13) -> mean_subtractor
     -> delta, delta-delta -> merge(39) -> normalization (mean, scale) -> lin_transform 39x39
+
+The device code (csrc/spkd_mfcc.hpp) computes THIS chain and no other: a configuration
+that names another topology, another merge order or other switches (power spectrum instead
+of magnitude, a zeroth cepstrum, no border copies) is refused here rather than silently
+turned into the shipped chain's features.
 """
 import re
 
@@ -63,9 +68,44 @@ class FeatureConfig(object):
         self.transform = mat.reshape(self.dim, self.dim)
         if self.dim != 3 * (self.n_cep + 1):
             raise ValueError('the chain gives %d features, the transform wants %d' % (3 * (self.n_cep + 1), self.dim))
-        if self.sample_rate % self.frame_rate:
-            raise ValueError('sample rate must be a multiple of the frame rate')
+        if self.sample_rate <= 0 or self.frame_rate <= 0 or self.sample_rate % self.frame_rate:
+            raise ValueError('sample rate must be a positive multiple of the frame rate')
         self.hop = self.sample_rate // self.frame_rate
+        self._check_supported(mods)
+
+    # (type, sources by module TYPE) of the one chain the device code computes, in file order
+    CHAIN = [('audiofile', []), ('fft', ['audiofile']), ('mel', ['fft']), ('power', ['fft']), ('dct', ['mel']),
+             ('merge', ['dct', 'power']), ('mean_subtractor', ['merge']), ('delta', ['mean_subtractor']),
+             ('delta', ['delta']), ('merge', ['mean_subtractor', 'delta', 'delta']),
+             ('normalization', ['merge']), ('lin_transform', ['normalization'])]
+
+    def _check_supported(self, mods):
+        """Raises ValueError unless the configuration is the supported chain with the supported
+        switches: magnitude 1, zeroth 0, copy_borders 1, n_mel / n_fft / window as built."""
+        for key, want in (('magnitude', 1), ('zeroth', 0), ('copy_borders', 1)):
+            if getattr(self, key) != want:
+                raise ValueError('feature configuration: %s %d is not supported (this build computes %s %d)'
+                                 % (key, getattr(self, key), key, want))
+        if self.window_width != 400 or self.n_cep != 12:
+            raise ValueError('feature configuration: this build does 400-sample windows and 12 cepstra')
+        by_name = {m['name'][0]: m for m in mods if 'name' in m}
+        got = []
+        for m in mods:
+            srcs = []
+            for nm in m.get('sources', []):
+                if nm not in by_name:
+                    raise ValueError('feature configuration: module %s reads unknown source %s' % (m.get('name', ['?'])[0], nm))
+                srcs.append(by_name[nm]['type'][0])
+            got.append((m['type'][0], srcs))
+        if got != self.CHAIN:
+            raise ValueError('feature configuration: unsupported module chain %r; this build computes %r' % (got, self.CHAIN))
+        # the second delta reads the first, the final merge is (cms, delta1, delta2) in that order
+        deltas = [m for m in mods if m['type'][0] == 'delta']
+        merges = [m for m in mods if m['type'][0] == 'merge']
+        cms = [m for m in mods if m['type'][0] == 'mean_subtractor'][0]['name'][0]
+        if deltas[1]['sources'] != [deltas[0]['name'][0]] or deltas[0]['sources'] != [cms] or \
+                merges[1]['sources'] != [cms, deltas[0]['name'][0], deltas[1]['name'][0]]:
+            raise ValueError('feature configuration: the delta / merge wiring differs from the supported chain')
 
     @classmethod
     def load(cls, path):

@@ -87,6 +87,34 @@ def _one_hip_runtime():
                 pass
 
 
+def mapped_hip_runtimes():
+    """The distinct libamdhip64 files mapped into this process (from /proc/self/maps)."""
+    found = set()
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if '/' in line else ''
+                if os.path.basename(path).startswith('libamdhip64.so'):
+                    found.add(os.path.realpath(path))
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def _check_one_runtime():
+    """After libspkd_hip.so is loaded exactly one HIP runtime must be mapped: the preload of
+    the PyTorch wheel's runtime only helps when its soname is the one this library was linked
+    against -- otherwise the loader brings in the system runtime as well, silently, which is
+    the very situation the preload is meant to prevent.  Two runtimes: an error
+    naming both, and the way out (SPKD_SYSTEM_HIP=1 for torch-free processes; importing torch
+    before this package otherwise)."""
+    rts = mapped_hip_runtimes()
+    if len(rts) > 1:
+        raise ImportError('two HIP runtimes are mapped into this process (%s): libspkd_hip.so and the PyTorch '
+                          'wheel link against different libamdhip64 sonames.  Set SPKD_SYSTEM_HIP=1 for a '
+                          'torch-free process, or import torch before this package.' % ', '.join(rts))
+
+
 def load_library(path=None):
     """Loads libspkd_hip.so; raises (never falls back) when it is missing."""
     global _lib
@@ -98,6 +126,7 @@ def load_library(path=None):
                           'g.build()"` (or make -C speaker-diarization_amd/csrc)' % p)
     _one_hip_runtime()
     lib = C.CDLL(p)
+    _check_one_runtime()
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     P = C.POINTER
     lib.spkd_abi_version.restype = C.c_int
@@ -351,10 +380,17 @@ class Context(object):
                                               C.c_void_p(d_dst)))
 
     def gw(self, d_frames, n_frames, begins, ends, params, log_cap=4096, tight=False, reuse=False,
-           seg_stats=None):
-        """tight=True sizes the event arrays for the typical case (a quarter of the
-        guaranteed bound) and transparently repeats the call with the full bound if
-        the device reports an overflow -- four times less data to allocate and copy.
+           seg_stats=None, first_guess_scale=1.0):
+        """Event capacity: spkd_gw_event_capacity_p is a FIRST GUESS, not a bound -- it counts
+        the scans of a window end that only moves forward, but after every detection the
+        reference resets the end to start + 2 * winsize (spk-change-detection.py:264-266) and
+        the window regrows over frames it has already scanned: a change point found early in a
+        long-grown window can make a turn need more scans than turn_len / step + 8.  The
+        kernel reports that safely (SPKD_EOVERFLOW, nothing written out of bounds) and the
+        call is repeated here with doubled capacities until it fits (the reference simply
+        produces output for such a turn; so does this).  tight=True starts from a quarter of
+        the first guess: four times less data to allocate and copy in the typical case.
+        first_guess_scale (tests): scales the first guess, to exercise the doubling.
         reuse=True returns views of per-context buffers: valid until the next gw call
         on this context.
         seg_stats: a callable n_records -> device pointer; turns the call into the fused
@@ -369,8 +405,11 @@ class Context(object):
         # == spkd_gw_event_capacity_p(len, params), vectorised
         step = min(0.2 * params.rate, 0.5 * params.rate, params.winstep)
         full = ((e - b).astype(np.float64) / step).astype(np.int64) + 8
+        if first_guess_scale != 1.0:
+            full = np.maximum((full * float(first_guess_scale)).astype(np.int64), 2)
+        grow = 1
         while True:
-            caps = (full // 4 + 8) if tight else full
+            caps = (full // 4 + 8) if tight else full * grow
             off = np.zeros(nt + 1, dtype=np.int64)
             off[1:] = np.cumsum(caps)
             nev = int(off[-1])
@@ -386,14 +425,14 @@ class Context(object):
             cnt = C.c_int64(0)
             if seg_stats is None:
                 st = self.lib.spkd_gw_ex(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
-                                         C.byref(params), _ptr(off), 0 if tight else 1, _ptr(n_win),
+                                         C.byref(params), _ptr(off), 0, _ptr(n_win),
                                          _ptr(win_maxd), _ptr(win_det), _ptr(det_start), _ptr(det_maxi),
                                          _ptr(det_d), _ptr(final_start), C.cast(log, C.c_void_p), log_cap,
                                          C.byref(cnt))
             else:
                 d_seg = seg_stats(nev)
                 st = self.lib.spkd_gw_fused(self.h, C.c_void_p(d_frames), n_frames, _ptr(b), _ptr(e), nt,
-                                            C.byref(params), _ptr(off), 0 if tight else 1, _ptr(n_win),
+                                            C.byref(params), _ptr(off), 0, _ptr(n_win),
                                             _ptr(win_maxd), _ptr(win_det), _ptr(det_start), _ptr(det_maxi),
                                             _ptr(det_d), _ptr(final_start), C.c_void_p(d_seg),
                                             C.cast(log, C.c_void_p), log_cap, C.byref(cnt))
@@ -401,7 +440,10 @@ class Context(object):
                 log_cap = int(cnt.value) + 16      # the run is deterministic: retry with room
                 continue
             if st == SPKD_EOVERFLOW and tight:
-                tight = False                      # an unusually busy turn: use the guaranteed bound
+                tight = False                      # an unusually busy turn: the full first guess
+                continue
+            if st == SPKD_EOVERFLOW and grow < 1024:
+                grow *= 2                          # a turn that re-scans (see above): double until it fits
                 continue
             self.check(st, allow=(SPKD_ENONFINITE,))
             break

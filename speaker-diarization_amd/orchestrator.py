@@ -24,94 +24,117 @@ from os import getcwd
 from subprocess import Popen, call
 from tempfile import gettempdir, mkstemp
 
+# ---- the contract as data -------------------------------------------------------------
+# command-line options: (flag, dest, default (a callable of the working directory), help)
+OPTIONS = [
+    ('-o', 'outfile', lambda cwd: 'stdout', 'Specifies an output recipe file, default stdout.'),
+    ('-fc', 'fcpath', lambda cwd: cwd, 'Specifies the path to feacat, defaults to ./'),
+    ('-fcfg', 'fcfg', lambda cwd: cwd + '/fconfig.cfg',
+     'Specifies the feacat acoustic model config, defaults ./fconfig.cfg'),
+    ('-lna', 'lnapath', lambda cwd: cwd + '/lna', 'Specifies the path to the lna files, defaults to ./lna'),
+    ('-exp', 'exppath', lambda cwd: cwd + '/exp', 'Specifies the path to the exp files, defaults to ./exp'),
+    ('-fp', 'feapath', lambda cwd: cwd + '/fea', 'Specifies the path to the feature files, defaults to ./fea'),
+    ('-tmp', 'tmppath', lambda cwd: '', 'Specifies where to write the temporal files, defaults to system temporary folder.'),
+]
+
+# directory checks in the order the reference makes them: (directory tested, directory named in
+# the refusal, progress line, directory named in the progress line).  The third check tests the
+# exp directory again where it means the feature directory (spk-diarization2.py:70-72): kept.
+DIR_CHECKS = [
+    ('lnapath', 'lnapath', 'Writing lna files in:', 'lnapath'),
+    ('exppath', 'exppath', 'Writing exp files in:', 'exppath'),
+    ('exppath', 'feapath', 'Writing features in:', 'feapath'),
+]
+
+# the serial tail of the pipeline: (progress line, argv template); {name} fields come from the
+# run's paths.  Every stage is ./<script> relative to the working directory.
+SERIAL_STAGES = [
+    ('Calling spk-change-detection.py',
+     ['./spk-change-detection.py', '{vad}', '{fea}', '-o', '{spkc}', '-m', 'gw', '-d', 'BIC', '-w', '1.0',
+      '-st', '3.0', '-dws', '0.1', '-l', '1.0']),
+    ('Calling spk-clustering.py', ['./spk-clustering.py', '{spkc}', '{fea}', '-o', '{out}', '-m', 'hi', '-l', '1.3']),
+]
+EXPORT_STAGES = [                                  # only when the output is a file
+    ('Calling aku2ann.py', ['./aku2ann.py', '{out}', '-o', '{stem}.ann']),
+    ('Calling aku2elan.py', ['./aku2elan.py', '{out}', '-o', '{stem}.eaf']),
+]
+EXP_STAGE = ['./generate_exp.py', '{init}', '-e', '{exp}', '-l', '{lna}']
+FEACAT_STAGE = ['{feacat}', '-c', '{fcfg}', '-H', '--raw-output', '{wav}']
+VAD_STAGE = ['./voice-detection2.py', '{init}', '{exp}', '-o', '{vad}', '-ms', '0.5', '-mns', '1.5']
+FFMPEG_STAGE = ['ffmpeg', '-i', '{media}', '-ar', '16000', '-ac', '1', '-ab', '32k', '{wav}']
+
+
+def _fill(template, paths):
+    return [t.format(**paths) for t in template]
+
+
+def _scratch_recipe(prefix, where):
+    return mkstemp(suffix='.recipe', prefix=prefix, dir=where)[1]
+
 
 def main(argv=None, say=None):
     if say is None:
         def say(*a):
             print(*a)
             sys.stdout.flush()
+    cwd = getcwd()
     parser = argparse.ArgumentParser(description='Process a media file to perform segmentation and '
                                                  'speaker clustering on it.')
     parser.add_argument('infile', type=str, help='Specifies the media file')
-    parser.add_argument('-o', dest='outfile', type=str, default='stdout',
-                        help='Specifies an output recipe file, default stdout.')
-    parser.add_argument('-fc', dest='fcpath', type=str, default=getcwd(),
-                        help='Specifies the path to feacat, defaults to ./')
-    parser.add_argument('-fcfg', dest='fcfg', type=str, default=getcwd() + '/fconfig.cfg',
-                        help='Specifies the feacat acoustic model config, defaults ./fconfig.cfg')
-    parser.add_argument('-lna', dest='lnapath', type=str, default=getcwd() + '/lna',
-                        help='Specifies the path to the lna files, defaults to ./lna')
-    parser.add_argument('-exp', dest='exppath', type=str, default=getcwd() + '/exp',
-                        help='Specifies the path to the exp files, defaults to ./exp')
-    parser.add_argument('-fp', dest='feapath', type=str, default=getcwd() + '/fea',
-                        help='Specifies the path to the feature files, defaults to ./fea')
-    parser.add_argument('-tmp', dest='tmppath', type=str, default='',
-                        help='Specifies where to write the temporal files, defaults to system temporary folder.')
-    args = parser.parse_args(argv)
+    for flag, dest, default, text in OPTIONS:
+        parser.add_argument(flag, dest=dest, type=str, default=default(cwd), help=text)
+    o = parser.parse_args(argv)
 
-    if not op.isfile(args.infile):
-        say('%s does not exist, exiting' % args.infile)
+    # ---- what must exist, said in the reference's words and order; a miss ends the run quietly
+    if not op.isfile(o.infile):
+        say('%s does not exist, exiting' % o.infile)
         return 0
-    say('Reading file:', args.infile)
-    outfile = args.outfile
-    say('Writing output to:', outfile)
-    args.fcpath = op.join(args.fcpath, 'feacat')
-    if not op.isfile(args.fcpath):
-        say('%s does not exist, exiting' % args.fcpath)
+    say('Reading file:', o.infile)
+    say('Writing output to:', o.outfile)
+    feacat = op.join(o.fcpath, 'feacat')
+    if not op.isfile(feacat):
+        say('%s does not exist, exiting' % feacat)
         return 0
-    say('Using feacat from:', args.fcpath)
-    if not op.isdir(args.tmppath):
-        args.tmppath = gettempdir()
-    say('Writing temporal files in:', args.tmppath)
-    if not op.isdir(args.lnapath):
-        say('Path %s does not exist, exiting' % args.lnapath)
-        return 0
-    say('Writing lna files in:', args.lnapath)
-    if not op.isdir(args.exppath):
-        say('Path %s does not exist, exiting' % args.exppath)
-        return 0
-    say('Writing exp files in:', args.exppath)
-    # (the reference tests exppath a second time here where it means feapath, :70-72)
-    if not op.isdir(args.exppath):
-        say('Path %s does not exist, exiting' % args.feapath)
-        return 0
-    say('Writing features in:', args.feapath)
+    say('Using feacat from:', feacat)
+    tmp = o.tmppath if op.isdir(o.tmppath) else gettempdir()
+    say('Writing temporal files in:', tmp)
+    for tested, named, line, shown in DIR_CHECKS:
+        if not op.isdir(getattr(o, tested)):
+            say('Path %s does not exist, exiting' % getattr(o, named))
+            return 0
+        say(line, getattr(o, shown))
 
-    if guess_type(args.infile)[0] != 'audio/x-wav':
+    paths = dict(media=o.infile, wav=o.infile, feacat=feacat, fcfg=o.fcfg, exp=o.exppath, lna=o.lnapath,
+                 fea=o.feapath, out=o.outfile)
+    if guess_type(o.infile)[0] != 'audio/x-wav':
         say('Media is not a .wav audio file, attempting to extract a .wav file')
         say('Calling ffmpeg')
-        infile = op.splitext(args.infile)[0] + '.wav'
-        call(['ffmpeg', '-i', args.infile, '-ar', '16000', '-ac', '1', '-ab', '32k', infile])
-    else:
-        infile = args.infile
+        paths['wav'] = op.splitext(o.infile)[0] + '.wav'
+        call(_fill(FFMPEG_STAGE, paths))
+    paths['init'] = _scratch_recipe('init', tmp)
+    with open(paths['init'], 'w') as f:
+        f.write('audio=' + paths['wav'] + '\n')
 
-    init_recipe = mkstemp(suffix='.recipe', prefix='init', dir=args.tmppath)[1]
-    with open(init_recipe, 'w') as f:
-        f.write('audio=' + infile + '\n')
-
+    # ---- the two producers side by side; the VAD recipe as soon as the .exp files are there
     say('Performing exp generation and feacat concurrently')
-    child1 = Popen(['./generate_exp.py', init_recipe, '-e', args.exppath, '-l', args.lnapath])
-    with open(op.join(args.feapath, op.splitext(op.basename(infile))[0] + '.fea'), 'w') as feafile:
-        child2 = Popen([args.fcpath, '-c', args.fcfg, '-H', '--raw-output', infile], stdout=feafile)
-        child1.wait()                                  # the exp files are needed first
+    decoder = Popen(_fill(EXP_STAGE, paths))
+    fea_file = op.join(o.feapath, op.splitext(op.basename(paths['wav']))[0] + '.fea')
+    with open(fea_file, 'w') as sink:
+        extractor = Popen(_fill(FEACAT_STAGE, paths), stdout=sink)
+        decoder.wait()
         say('Calling voice-detection2.py')
-        vad_recipe = mkstemp(suffix='.recipe', prefix='vad', dir=args.tmppath)[1]
-        call(['./voice-detection2.py', init_recipe, args.exppath, '-o', vad_recipe, '-ms', '0.5', '-mns', '1.5'])
+        paths['vad'] = _scratch_recipe('vad', tmp)
+        call(_fill(VAD_STAGE, paths))
         say('Waiting for feacat to end.')
-        child2.wait()
+        extractor.wait()
 
-    spkchange_recipe = mkstemp(suffix='.recipe', prefix='spkc', dir=args.tmppath)[1]
-    say('Calling spk-change-detection.py')
-    call(['./spk-change-detection.py', vad_recipe, args.feapath, '-o', spkchange_recipe, '-m', 'gw', '-d', 'BIC',
-          '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0'])
-    say('Calling spk-clustering.py')
-    call(['./spk-clustering.py', spkchange_recipe, args.feapath, '-o', outfile, '-m', 'hi', '-l', '1.3'])
-
-    if outfile != 'stdout':
-        outf = op.splitext(op.basename(outfile))[0]
-        outfpath = op.dirname(outfile)
-        say('Calling aku2ann.py')
-        call(['./aku2ann.py', outfile, '-o', op.join(outfpath, outf + '.ann')])
-        say('Calling aku2elan.py')
-        call(['./aku2elan.py', outfile, '-o', op.join(outfpath, outf + '.eaf')])
+    # ---- the hot path, then the exports; return codes are not looked at (like the reference)
+    paths['spkc'] = _scratch_recipe('spkc', tmp)
+    stages = list(SERIAL_STAGES)
+    if o.outfile != 'stdout':
+        paths['stem'] = op.join(op.dirname(o.outfile), op.splitext(op.basename(o.outfile))[0])
+        stages += EXPORT_STAGES
+    for line, template in stages:
+        say(line)
+        call(_fill(template, paths))
     return 0

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/feaconfig.json: the PARAMETERS of the reference's feature
-configuration (fconfig.cfg:1-101) as parsed by speaker-diarization_amd/feaconfig.py.
-Runs only where /root/reference exists; the configuration file itself is not copied."""
+"""Writes tests/golden/feaconfig.json: the STRUCTURAL parameters of the reference's feature
+configuration (fconfig.cfg:1-101) as parsed by speaker-diarization_amd/feaconfig.py, and a
+SHA-256 of its trained arrays (normalization mean / scale, the 39x39 transform: 1 599
+numbers of model data, which are NOT stored -- ADVICE r2).  Runs only where /root/reference
+exists; the tests read the real arrays from there when it does and use synthetic ones
+otherwise."""
+import hashlib
+
+import numpy as np
 import importlib
 import json
 import os
@@ -18,10 +24,12 @@ def main():
     d = dict(sample_rate=cfg.sample_rate, frame_rate=cfg.frame_rate, window_width=cfg.window_width,
              pre_emph=cfg.pre_emph, copy_borders=cfg.copy_borders, magnitude=cfg.magnitude, n_cep=cfg.n_cep,
              zeroth=cfg.zeroth, cms_left=cfg.cms_left, cms_right=cfg.cms_right, delta_width=cfg.delta_width,
-             delta_norm=cfg.delta_norm, dim=cfg.dim, mean=[float(x) for x in cfg.mean],
-             scale=[float(x) for x in cfg.scale], transform=[float(x) for x in cfg.transform.ravel()],
-             source="parameters parsed from the reference's fconfig.cfg:1-101 by speaker-diarization_amd/feaconfig.py "
-                    "(tests/golden/make_golden_feaconfig.py); the file itself is not copied")
+             delta_norm=cfg.delta_norm, dim=cfg.dim,
+             arrays_sha256=hashlib.sha256(np.concatenate([cfg.mean, cfg.scale, cfg.transform.ravel()])
+                                          .astype('<f4').tobytes()).hexdigest(),
+             source="structural parameters parsed from the reference's fconfig.cfg:1-101 by "
+                    "speaker-diarization_amd/feaconfig.py (tests/golden/make_golden_feaconfig.py); the trained "
+                    "arrays (mean, scale, transform) are represented by the SHA-256 of their float32 values only")
     with open(os.path.join(HERE, 'feaconfig.json'), 'w') as f:
         json.dump(d, f, indent=1)
 

@@ -123,5 +123,7 @@ def test_bench_gpus_flag_starts_ranks_without_a_launcher():
                         '--files', '1', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-extras'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
-    assert r.stderr.count('bench.py needs an MI355X') >= 2, r.stderr[-2000:]
-    assert 'local_rank: 1' in r.stderr or 'rank      : 1' in r.stderr or '[1]' in r.stderr, r.stderr[-2000:]
+    # (the launcher stops the other rank as soon as the first one has failed: one message is
+    # certain, and its failure report names both local ranks)
+    assert r.stderr.count('bench.py needs an MI355X') >= 1, r.stderr[-2000:]
+    assert 'local_rank: 0' in r.stderr and 'local_rank: 1' in r.stderr, r.stderr[-2000:]

@@ -16,12 +16,28 @@ from conftest import pkg
 from helpers import ROOT
 
 GOLD = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'feaconfig.json')))
+REF_CFG = os.path.join(os.environ.get('SPKD_REFERENCE', '/root/reference'), 'fconfig.cfg')
+
+
+def _arrays():
+    """The trained arrays of the chain (normalization mean / scale, 39x39 transform).  The
+    reference's own are model data and are not stored in this repository (only their SHA-256 is,
+    tests/golden/feaconfig.json): synthetic ones of the same shapes and magnitudes stand in --
+    nothing here pins the numbers anyway (PARITY UNPINNED)."""
+    rng = np.random.default_rng(39)
+    dim = GOLD['dim']
+    mean = np.zeros(dim)
+    scale = 0.15 + 0.05 * np.arange(dim) + 0.01 * rng.random(dim)
+    transform = np.eye(dim) + 0.1 * rng.standard_normal((dim, dim))
+    return mean, scale, transform.ravel()
 
 
 def _cfg_text(g):
     """A configuration file in the feacat grammar with the golden parameters (written
     from scratch: module order and names as the chain needs them)."""
     nums = lambda v: ' '.join(repr(float(x)) for x in v)
+    mean, scale, transform = _arrays()
+    g = dict(g, mean=mean, scale=scale, transform=transform)
     return '\n'.join([
         'module\n{\n  name audiofile\n  type audiofile\n  pre_emph_coef %r\n  sample_rate %d\n  frame_rate %d\n'
         '  window_width %d\n  copy_borders %d\n  raw 1\n}' % (g['pre_emph'], g['sample_rate'], g['frame_rate'],
@@ -62,10 +78,38 @@ def test_config_reader_round_trips_the_reference_parameters(cfg):
     assert (cfg.sample_rate, cfg.frame_rate, cfg.window_width, cfg.hop) == (16000, 125, 400, 128)
     assert (cfg.n_cep, cfg.cms_left, cfg.cms_right, cfg.dim) == (12, 75, 75, 39)
     assert cfg.delta_width == [2, 2] and cfg.delta_norm == [1.0, 10.0] and cfg.pre_emph == pytest.approx(0.97)
-    assert np.allclose(cfg.scale, GOLD['scale']) and np.allclose(cfg.transform.ravel(), GOLD['transform'])
+    mean, scale, transform = _arrays()
+    assert np.allclose(cfg.scale, scale) and np.allclose(cfg.transform.ravel(), transform) and np.allclose(cfg.mean, mean)
     with pytest.raises(ValueError):
         pkg('feaconfig').FeatureConfig('module\n{\n  name a\n  type audiofile\n  sample_rate 16000\n  frame_rate 125\n'
                                        '  window_width 400\n}\n')
+
+
+def test_unsupported_configurations_are_refused_not_reinterpreted():
+    """A configuration whose switches or module chain differ from the one the device code
+    computes must raise, not silently yield the shipped chain's features."""
+    fc = pkg('feaconfig')
+    good = _cfg_text(GOLD)
+    fc.FeatureConfig(good)
+    for a, b in (('magnitude 1', 'magnitude 0'), ('zeroth 0', 'zeroth 1'), ('copy_borders 1', 'copy_borders 0'),
+                 ('sources mfcc power', 'sources power mfcc'), ('sources cms delta1 delta2', 'sources delta1 cms delta2'),
+                 ('sources delta1\n', 'sources cms\n'), ('window_width 400', 'window_width 320'),
+                 ('sample_rate 16000', 'sample_rate 0')):
+        assert a in good
+        with pytest.raises((ValueError, ZeroDivisionError)):
+            fc.FeatureConfig(good.replace(a, b))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='the reference tree is not on this machine')
+def test_reference_configuration_file_parses_to_the_golden_parameters():
+    import hashlib
+    c = pkg('feaconfig').FeatureConfig.load(REF_CFG)
+    for k in ('sample_rate', 'frame_rate', 'window_width', 'copy_borders', 'magnitude', 'n_cep', 'zeroth',
+              'cms_left', 'cms_right', 'delta_width', 'delta_norm', 'dim'):
+        assert getattr(c, k) == GOLD[k], k
+    assert c.pre_emph == pytest.approx(GOLD['pre_emph'])
+    arr = np.concatenate([c.mean, c.scale, c.transform.ravel()]).astype('<f4').tobytes()
+    assert hashlib.sha256(arr).hexdigest() == GOLD['arrays_sha256']
 
 
 def test_numpy_restatement_has_the_properties_of_an_mfcc_chain(cfg):

@@ -38,6 +38,33 @@ def _run_scripts(tmp, engine, tag, variant=1):
     return open(spkc).read(), open(final).read(), out1.getvalue(), out2.getvalue()
 
 
+def _merge_term_scales(feats, spkc_text, merges, lambdac=1.3):
+    """Size of the terms each BIC merge distance is a difference of: the merge log (compacted
+    indices, spk-clustering.py:204-217) replayed on the segments' statistics records, the
+    three log dets of every merged pair from the oracle's pair function."""
+    import ctypes as C
+    from oracle.c_engine import COracleEngine
+    orc = COracleEngine(1)
+    orc.set_features(feats)
+    segs = [(int(float(a) * 125.0), int(float(b) * 125.0)) for a, b in
+            re.findall(r'start-time=(\S+) end-time=(\S+)', spkc_text)]
+    recs = list(orc.stats([[s_] for s_ in segs]))
+    out8 = np.zeros(8, dtype=np.float64)
+    scales = []
+    for a, b in merges:                         # (printed 1-based, spk-clustering.py:214)
+        a, b = a - 1, b - 1
+        ra, rb = np.ascontiguousarray(recs[a]), np.ascontiguousarray(recs[b])
+        rc = orc.lib.orc_pair_terms(C.c_void_p(ra.ctypes.data), C.c_void_p(rb.ctypes.data), 0, 0, None, None,
+                                    C.c_void_p(out8.ctypes.data))
+        assert rc == 0
+        n1, n2, l1, l2, lx = out8[:5]
+        n = n1 + n2
+        scales.append(0.5 * n * abs(lx) + 0.5 * n1 * abs(l1) + 0.5 * n2 * abs(l2) + lambdac * 0.5 * 819.0 * np.log(n))
+        recs[a] = ra + rb
+        del recs[b]
+    return scales
+
+
 def _merge_lines(text):
     return [(int(a), int(b), float(d)) for a, b, d in
             re.findall(r'Merging: (\d+) and (\d+) distance: (\S+)', text)]
@@ -480,4 +507,12 @@ def test_ten_hour_file_matches_c_oracle(tmp_path):
     # of terms of 1e8, so 1e-8 relative on the distance is 1e-13 on the terms (bar: 1e-5)
     worst = max(abs(x[2] - y[2]) / max(1.0, abs(y[2])) for x, y in zip(mh, mo))
     assert worst < 1e-7, worst
-    print('10 h: %d turns, %d merges, worst merge-distance rel err %.2g' % (h[0].count('\n'), len(mh), worst))
+    # ... and pinned against what it is a difference OF (the bound above was 1e-8 until a run
+    # measured 1.26e-8): every merge distance within 1e-12 of the size of its own terms,
+    #   0.5 N |log det S| + 0.5 N1 |log det S1| + 0.5 N2 |log det S2| + penalty,
+    # the terms taken from the oracle's pair function on the clusters the merge log replays
+    scales = _merge_term_scales(feats, h[0], [(a, b) for a, b, _ in mo])
+    worst_t = max(abs(x[2] - y[2]) / t for x, y, t in zip(mh, mo, scales))
+    assert worst_t < 1e-12, worst_t
+    print('10 h: %d turns, %d merges, worst merge-distance rel err %.2g (%.2g of its terms)' % (
+        h[0].count('\n'), len(mh), worst, worst_t))

@@ -361,3 +361,34 @@ def test_non_finite_covariance_raises_like_the_reference_but_writes_nothing(eng,
         cli.main_clustering([good, os.path.join(tmp, 'fea') + '/', '-o', os.path.join(tmp, 'out.recipe'),
                              '-m', 'hi', '-l', '1.3'], variant=1, engine=eng, stdout=said)
     assert 'Merging:' not in said.getvalue()
+
+
+def test_event_capacity_is_a_first_guess_that_doubles_until_it_fits(eng):
+    """spkd_gw_event_capacity_p counts the scans of a window end that only moves forward; a
+    turn that re-scans (a detection resets the end, spk-change-detection.py:264-266) can need
+    more, is told SPKD_EOVERFLOW, and must still produce output like the reference does
+    (ADVICE r2).  Data that breaks the guess is pathological and hard to synthesise, so the
+    doubling is exercised from the other side: the first guess scaled down 64 times (2 event
+    slots for most turns) must end in exactly the result of the ordinary call."""
+    hipabi = pkg('hipabi')
+    feats, vad, _ = session({'seed': 7001, 'seconds': 400, 'n_speakers': 4, 'kwargs': {},
+                             'frames': 50000, 'sha256': json.load(open(os.path.join(
+                                 ROOT, 'tests/golden/functions.json')))['session']['sha256']})
+    eng.set_features(feats)
+    b = np.array([s for (s, e) in vad], dtype=np.int64)
+    e = np.array([e_ for (s, e_) in vad], dtype=np.int64)
+    p = hipabi.CdParams(hipabi.KINDS['BIC'], 0, 1.0, 0.0, 125.0, 375.0, 12.0, 125.0)
+    ref = eng.ctx.gw(eng.d_frames, eng.n_frames, b, e, p)
+    small = eng.ctx.gw(eng.d_frames, eng.n_frames, b, e, p, first_guess_scale=1.0 / 64)
+    assert int(small['off'][-1]) > 0 and int(ref['n_win'].max()) > 2      # the scaled guess was too small
+    assert np.array_equal(ref['n_win'], small['n_win'])
+    assert np.array_equal(ref['final_start'], small['final_start'])
+    for t in range(len(b)):
+        n, o1, o2 = int(ref['n_win'][t]), int(ref['off'][t]), int(small['off'][t])
+        assert np.array_equal(ref['win_det'][o1:o1 + n], small['win_det'][o2:o2 + n])
+        assert np.array_equal(ref['win_maxd'][o1:o1 + n], small['win_maxd'][o2:o2 + n], equal_nan=True)
+        nd = int(ref['win_det'][o1:o1 + n].sum())
+        for k in ('det_start', 'det_maxi', 'det_d'):
+            assert np.array_equal(ref[k][o1:o1 + nd], small[k][o2:o2 + nd])
+    # capacities the kernel would have refused at the first try
+    assert int(small['off'][-1]) >= int(ref['n_win'].sum())
