@@ -979,6 +979,7 @@ spkd_status spkd_mfcc(spkd_ctx* c, const int16_t* d_pcm, int64_t n_samples, cons
                                 MP_FR * MF_DIM + MF_DIM * MF_DIM) * sizeof(float);
     if (lds > 60 * 1024) return fail(c, SPKD_EINVAL, "mfcc: mean-subtraction window too wide for the LDS tile");
     const int64_t T = n_samples / hop;
+    *h_n_frames = T;
     if (T == 0) return SPKD_OK;
     if (!d_pcm || !d_features) return fail(c, SPKD_EINVAL, "mfcc: null device buffer");
     spkd_status st = begin_call(c);
