@@ -152,11 +152,16 @@ template <int NW>
 __device__ __forceinline__ void sweep_dump_lds(double* rec, const SweepLane& SL, const double (&acc)[Gw<NW>::NACC]) {
     using G = Gw<NW>;
     if (!SL.on) return;
+    // (opaque copies: the addresses are formed HERE, per call -- hoisted out of the sweep loop
+    // they are sixteen more live values, spilled, and every reload waits on vmcnt for the record
+    // dumps and the tile prefetch in flight)
+    int bi = SL.bi, bj = SL.bj;
+    asm volatile("" : "+v"(bi), "+v"(bj));
 #pragma unroll
     for (int u = 0; u < G::BR; ++u)
 #pragma unroll
         for (int v = 0; v < G::BC; ++v) {
-            const int r = G::BR * SL.bi + u, j = G::BC * SL.bj + v;
+            const int r = G::BR * bi + u, j = G::BC * bj + v;
             if (r >= j) rec[tri_slot(r, j)] = acc[u * G::BC + v];
         }
 }
@@ -164,12 +169,17 @@ __device__ __forceinline__ void sweep_dump_lds(double* rec, const SweepLane& SL,
 template <int NW>
 __device__ __forceinline__ void sweep_gather_lds(const double* rec, const SweepLane& SL, double (&acc)[Gw<NW>::NACC]) {
     using G = Gw<NW>;
+    int bi = SL.bi, bj = SL.bj;
+    asm volatile("" : "+v"(bi), "+v"(bj));
+    // (branch-free: entries outside the triangle read a valid slot and are zeroed)
 #pragma unroll
     for (int u = 0; u < G::BR; ++u)
 #pragma unroll
         for (int v = 0; v < G::BC; ++v) {
-            const int r = G::BR * SL.bi + u, j = G::BC * SL.bj + v;
-            acc[u * G::BC + v] = (SL.on && r >= j) ? rec[tri_slot(r, j)] : 0.0;
+            const int r = G::BR * bi + u, j = G::BC * bj + v;
+            const bool in = SL.on && r >= j;
+            const double x = rec[tri_slot(r >= j ? r : j, r >= j ? j : r)];     // (by symmetry always a valid slot)
+            acc[u * G::BC + v] = in ? x : 0.0;
         }
 }
 
@@ -178,7 +188,9 @@ __device__ __forceinline__ void sweep_dump_packed(SPKD_GLOBAL double* rec, const
                                                   const double (&acc)[Gw<NW>::NACC]) {
     using G = Gw<NW>;
     if (!SL.on) return;
-    const int r0 = G::BR * SL.bi, j0 = G::BC * SL.bj;
+    int bi = SL.bi, bj = SL.bj;
+    asm volatile("" : "+v"(bi), "+v"(bj));              // (see sweep_dump_lds)
+    const int r0 = G::BR * bi, j0 = G::BC * bj;
     if (!SL.diag) {
 #pragma unroll
         for (int v = 0; v < G::BC; ++v) {
@@ -199,12 +211,17 @@ template <int NW>
 __device__ __forceinline__ void sweep_gather_packed(const SPKD_GLOBAL double* rec, const SweepLane& SL,
                                                     double (&acc)[Gw<NW>::NACC]) {
     using G = Gw<NW>;
-    const int r0 = G::BR * SL.bi, j0 = G::BC * SL.bj;
+    int bi = SL.bi, bj = SL.bj;
+    asm volatile("" : "+v"(bi), "+v"(bj));
+    const int r0 = G::BR * bi, j0 = G::BC * bj;
 #pragma unroll
     for (int v = 0; v < G::BC; ++v)
 #pragma unroll
-        for (int u = 0; u < G::BR; ++u)
-            acc[u * G::BC + v] = (r0 + u >= j0 + v) ? rec[pk_low(r0 + u, j0 + v)] : 0.0;
+        for (int u = 0; u < G::BR; ++u) {
+            const int r = r0 + u, j = j0 + v;
+            const double x = rec[r >= j ? pk_low(r, j) : pk_low(j, r)];         // (by symmetry always inside the record)
+            acc[u * G::BC + v] = r >= j ? x : 0.0;
+        }
 }
 
 // Adds the turn frames [pos, ...) to acc in frame order.  `want` is the next
@@ -278,10 +295,14 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
             const int tl = (int)((limit - pos) < G::TILE ? (limit - pos) : G::TILE);
             SW_TICK(0);
             __syncthreads();                     // the previous tile is no longer read
-            // (slots beyond tl * D hold element 0: they land in tile rows >= tl, never read)
+            // (slots beyond tl * D hold element 0: they land in tile rows >= tl, never read;
+            // the LDS addresses are formed here, from an opaque copy of the thread index: kept
+            // across the loop they are STAGE more live values, spilled, see sweep_dump_lds)
+            int ts = t;
+            asm volatile("" : "+v"(ts));
 #pragma unroll
             for (int u = 0; u < G::STAGE; ++u) {
-                const int idx = t + u * G::TPB;
+                const int idx = ts + u * G::TPB;
                 const int f = idx / D, c = idx - f * D;
                 if (u < G::STAGE - 1 || idx < G::TILE * D) xs[f * DA + c] = st[u];
             }
