@@ -1313,4 +1313,460 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_final(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// The wide form without hand-offs ("step" chain): one launch per merge, NO workgroup waits
+// for or signals another one inside a launch -- the only synchronisation is the kernel
+// boundary.  The selection of merge k (the O(N) pass over the row caches, the stop decision,
+// the partner list, the merged record) is done REDUNDANTLY by every workgroup of round k from
+// what round k - 1 left; the code and the reduction order are the same everywhere, so every
+// workgroup arrives at the same merge.  What the round-k workgroups write is kept apart from
+// what round k reads:
+//   * row caches and the scalar state are double-buffered by the parity of k;
+//   * the new row of the matrix also goes to a staging row (parity of k), which is what the
+//     next selection reads -- row sa of the matrix itself gets its symmetric entries written
+//     while slow workgroups may still be selecting;
+//   * a dead cluster is marked with the ROUND it died in (alive at the start of round k:
+//     death >= k), so the mark may land at any time during the round;
+//   * a merged record goes to a fresh slot (N + k - 1); a cluster's current slot is one 64-bit
+//     word (round | new | old) that reads correctly before and after workgroup 0 replaces it.
+// Against the ticket form (k_ahc_round: release fence, ticket, acquire fence, then one
+// workgroup selects while the others have left) a merge loses ~4 us of fences and atomics and
+// three dependent passes of the last arriver: 25.5 -> ~16 us per merge at N = 380.
+// Arithmetic, tie-breaks and NaN rules are those of k_ahc; results are bit-identical.
+// ---------------------------------------------------------------------------
+constexpr int STEP_WAVES = 4;
+constexpr int STEP_TPB = STEP_WAVES * WAVE;
+constexpr int STEP_PARTNERS = 4 * STEP_WAVES - 1;          // + the merged cluster itself: 16 items, one wave pass each
+constexpr int ALIVE_ROUND = 0x7fffffff;
+constexpr int STEP_MAX_N = 16384;                          // (two int arrays of N in LDS)
+
+struct StepState {
+    int32_t done, n_merges;
+    long long psa;           // the row the previous round rewrote (-1: none)
+    double fmin;
+};
+
+__host__ __device__ inline unsigned long long step_slot_word(int round, int new_slot, int old_slot) {
+    return ((unsigned long long)(unsigned)round << 40) | ((unsigned long long)(unsigned)new_slot << 20) |
+           (unsigned long long)(unsigned)old_slot;
+}
+__device__ __forceinline__ int step_slot_of(unsigned long long w, int k) {
+    return ((int)(w >> 40) < k) ? (int)((w >> 20) & 0xfffffull) : (int)(w & 0xfffffull);
+}
+
+struct StepArrays {
+    double* ex;              // initial records, quad layout (slots 0 .. N - 1 of a problem)
+    double* pk;              //                  packed
+    double* exm;             // merged records (slot N + m of a problem = record off + m here)
+    double* pkm;
+    int32_t* death;
+    double* rmin2;           // [2][n_total]
+    int32_t* rarg2;          // [2][n_total]
+    int32_t* rnan2;          // [2][n_total]
+    double* newrow2;         // [2][n_total]
+    unsigned long long* sw;  // [n_total]
+    StepState* state2;       // [2][n_prob]
+    int64_t n_total;
+    int32_t n_prob;
+};
+
+// row caches of the full initial matrix -> buffer 1 (what round 1 reads), every cluster alive,
+// every cluster in its own slot.  grid (ceil(n_max / 8), n_prob), AHC_TPB threads.
+__global__ __launch_bounds__(AHC_TPB) void k_step_init(
+        const int64_t* __restrict__ seg_off, const double* __restrict__ mat,
+        const int64_t* __restrict__ mat_off, StepArrays Q) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int p = blockIdx.y;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        StepState S;
+        S.done = 0; S.n_merges = 0; S.psa = -1; S.fmin = 0.0;
+        Q.state2[(size_t)1 * Q.n_prob + p] = S;
+        Q.state2[(size_t)0 * Q.n_prob + p] = S;
+    }
+    const long long r = (long long)blockIdx.x * AHC_WAVES + wave;
+    if (r >= N) return;
+    double mv;
+    int mc, nc;
+    ahc_scan_row(mat + mat_off[p] + r * N, N, nullptr, true, -1, 0.0, lane, mv, mc, nc);
+    if (lane == 0) {
+        Q.rmin2[Q.n_total + off + r] = mv;
+        Q.rarg2[Q.n_total + off + r] = mc;
+        Q.rnan2[Q.n_total + off + r] = nc;
+        Q.death[off + r] = ALIVE_ROUND;
+        Q.sw[off + r] = step_slot_word(0, (int)r, (int)r);
+    }
+}
+
+// wave-wide (min, first column, first NaN column) of one row over the clusters alive AFTER
+// merge k (death > k, and not sb: its mark may not have landed yet); sub_col as in ahc_scan_row
+__device__ __forceinline__ void step_scan_row(const double* __restrict__ row, long long N,
+                                              const int32_t* __restrict__ death, int k, long long sb,
+                                              long long sub_col, double sub_val, int lane,
+                                              double& mv, int& mc, int& nc) {
+    mv = __builtin_huge_val();
+    mc = NO_COL; nc = NO_COL;
+    for (long long c0 = 0; c0 < N; c0 += 4 * WAVE) {
+        double v[4];
+        int a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long c = c0 + u * WAVE + lane;
+            const long long cc = c < N ? c : N - 1;
+            a[u] = (c < N && c != sb) ? (death[cc] > k ? 1 : 0) : 0;
+            v[u] = row[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long cl = c0 + u * WAVE + lane;
+            const int c = (int)cl;
+            if (!a[u]) continue;
+            const double x = (cl == sub_col) ? sub_val : v[u];
+            if (x != x) { if (c < nc) nc = c; continue; }
+            if (x < mv || (x == mv && c < mc)) { mv = x; mc = c; }
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double v2 = __shfl_xor(mv, s);
+        const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+        if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+        nc = n2 < nc ? n2 : nc;
+    }
+}
+
+// round k (k = 1 .. n_max - 1): merge k of every problem that has not stopped.
+// grid (max(1, ceil((n_max - k - 1) / STEP_PARTNERS)), n_prob); dynamic LDS: 2 N_max ints.
+template <bool TWO>
+__global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
+        int k, const int64_t* __restrict__ seg_off, int variant, int kind, int max_spk, double lambdac,
+        double threshold, double* __restrict__ ld, double* __restrict__ aux,
+        double* __restrict__ mat, const int64_t* __restrict__ mat_off, StepArrays Q,
+        int32_t* __restrict__ out_a, int32_t* __restrict__ out_b, double* __restrict__ out_d,
+        unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
+    extern __shared__ int32_t s_dyn[];               // [N] partner list | [N] current slot of a cluster (-1: dead)
+    __shared__ double ldsA[QREC];
+    __shared__ double s_auxA[AUX];
+    __shared__ double s_ldx[4 * STEP_WAVES];
+    __shared__ double s_dfin[4 * STEP_WAVES];
+    __shared__ int s_rescan[4 * STEP_WAVES];
+    struct RowRed { double mv, wmax, wmin; int mc, nc; };
+    __shared__ RowRed rred[STEP_WAVES];
+    __shared__ ArgMin red[STEP_WAVES];
+    __shared__ ArgMin best;
+    __shared__ RowRed s_psa;
+    __shared__ int s_cnt[2];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const QuadLane L = quad_lane();
+    const int p = blockIdx.y;
+    const StepState S = Q.state2[(size_t)(k & 1) * Q.n_prob + p];
+    StepState* Snext = Q.state2 + (size_t)((k + 1) & 1) * Q.n_prob + p;
+    const bool lead = blockIdx.x == 0;
+    if (S.done) {                                    // a stopped problem: carry its state forward
+        if (lead && tid == 0) *Snext = S;
+        return;
+    }
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    const int n_merges = S.n_merges;
+    const long long psa = S.psa;
+    const long long m = N - n_merges;                // clusters alive now
+    const int n_part = (int)(m - 2);                 // partners of this merge, if it happens
+    const int nb = n_part > 0 ? (n_part + STEP_PARTNERS - 1) / STEP_PARTNERS : 1;
+    if ((int)blockIdx.x >= nb) return;
+    int32_t* s_ids = s_dyn;
+    int32_t* s_slot = s_dyn + N;
+    const int rb = k & 1, wb = (k + 1) & 1;
+    const int32_t* death = Q.death + off;
+    const double* rmin_r = Q.rmin2 + (size_t)rb * Q.n_total + off;
+    const int32_t* rarg_r = Q.rarg2 + (size_t)rb * Q.n_total + off;
+    const int32_t* rnan_r = Q.rnan2 + (size_t)rb * Q.n_total + off;
+    double* rmin_w = Q.rmin2 + (size_t)wb * Q.n_total + off;
+    int32_t* rarg_w = Q.rarg2 + (size_t)wb * Q.n_total + off;
+    int32_t* rnan_w = Q.rnan2 + (size_t)wb * Q.n_total + off;
+    const double* newrow_r = Q.newrow2 + (size_t)((k - 1) & 1) * Q.n_total + off;
+    double* newrow_w = Q.newrow2 + (size_t)(k & 1) * Q.n_total + off;
+    double* Dm = mat + mat_off[p];
+    double* ldp = ld + off;
+    const long long INF_IDX = 0x7fffffffffffffffLL;
+    auto rec_quad = [&](int slot) -> const double* {
+        return slot < N ? Q.ex + (off + slot) * QREC : Q.exm + (off + (slot - N)) * QREC;
+    };
+    auto rec_packed = [&](int slot) -> const double* {
+        return slot < N ? Q.pk + (off + slot) * REC : Q.pkm + (off + (slot - N)) * REC;
+    };
+    // ---- S. the selection, by every workgroup: ONE pass over x = 0 .. N - 1 -- x as a column
+    // of the row psa (its fresh cache; variant 1: the running statistics over the distances
+    // round k - 1 evaluated) and x as a row of the arg-min over the row caches
+    const double diag_psa = psa >= 0 ? Dm[psa * N + psa] : 0.0;
+    double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
+    int mc = NO_COL, nc = NO_COL;
+    ArgMin mine;
+    mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+#pragma unroll 2
+    for (long long x = tid; x < N; x += STEP_TPB) {
+        const int dth = death[x];
+        const unsigned long long w = Q.sw[off + x];
+        const double dn = newrow_r[x];
+        const double v = rmin_r[x];
+        const int c = rarg_r[x], rn = rnan_r[x];
+        const bool a = dth >= k;
+        s_slot[x] = a ? step_slot_of(w, k) : -1;
+        if (!a) continue;
+        if (psa >= 0) {
+            const double d = x == psa ? diag_psa : dn;
+            if (variant == 1 && x != psa && stat_valid(d)) {
+                wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                wmin = (wmin != wmin || d < wmin) ? d : wmin;
+            }
+            if (d != d) { if ((int)x < nc) nc = (int)x; }
+            else if (d < mv || (d == mv && (int)x < mc)) { mv = d; mc = (int)x; }
+        }
+        if (x != psa) {
+            if (rn != NO_COL) { const long long l = x * N + rn; if (l < mine.nan_idx) mine.nan_idx = l; }
+            if (c != NO_COL) {
+                const long long l = x * N + c;
+                if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double v2 = __shfl_xor(mv, s);
+        const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
+        if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
+        nc = n2 < nc ? n2 : nc;
+        const double x = __shfl_xor(wmax, s), y = __shfl_xor(wmin, s);
+        if (x == x && (wmax != wmax || x > wmax)) wmax = x;
+        if (y == y && (wmin != wmin || y < wmin)) wmin = y;
+        ArgMin o;
+        o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
+        argmin_merge(mine, o);
+    }
+    if (lane == 0) {
+        rred[wave].mv = mv; rred[wave].mc = mc; rred[wave].nc = nc; rred[wave].wmax = wmax; rred[wave].wmin = wmin;
+        red[wave] = mine;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ArgMin b = red[0];
+        for (int w = 1; w < STEP_WAVES; ++w) argmin_merge(b, red[w]);
+        RowRed f = rred[0];
+        if (psa >= 0) {
+            for (int w = 1; w < STEP_WAVES; ++w) {
+                const RowRed o = rred[w];
+                if (o.mv < f.mv || (o.mv == f.mv && o.mc < f.mc)) { f.mv = o.mv; f.mc = o.mc; }
+                f.nc = o.nc < f.nc ? o.nc : f.nc;
+                if (o.wmax == o.wmax && (f.wmax != f.wmax || o.wmax > f.wmax)) f.wmax = o.wmax;
+                if (o.wmin == o.wmin && (f.wmin != f.wmin || o.wmin < f.wmin)) f.wmin = o.wmin;
+            }
+            if (lead && variant == 1) {
+                if (f.wmax == f.wmax) atomicMax(stat_max + p, dkey(f.wmax));
+                if (f.wmin == f.wmin) atomicMin(stat_min + p, dkey(f.wmin));
+            }
+            ArgMin own;                              // row psa as a candidate of the arg-min
+            own.v = f.mc != NO_COL ? f.mv : __builtin_huge_val();
+            own.idx = f.mc != NO_COL ? psa * N + f.mc : INF_IDX;
+            own.nan_idx = f.nc != NO_COL ? psa * N + f.nc : INF_IDX;
+            argmin_merge(b, own);
+        }
+        s_psa = f;
+        best = b;
+    }
+    __syncthreads();
+    const bool has_nan = best.nan_idx != INF_IDX;
+    const double mind = has_nan ? __builtin_nan("") : best.v;
+    const long long index = has_nan ? best.nan_idx : best.idx;
+    const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
+    const long long r0 = index / N, c0 = index - r0 * N;
+    if (!go || r0 == c0) {
+        if (lead && tid == 0) {
+            if (go) atomicOr(err, ERR_DEGENERATE_MERGE);
+            StepState T;
+            T.done = 1; T.n_merges = n_merges; T.psa = psa; T.fmin = mind;
+            *Snext = T;
+        }
+        return;
+    }
+    const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
+    // ---- partner list, in ascending slot order (the same in every workgroup), and the merge's
+    // compacted indices = alive slots in front: wave 0, a ballot per 64 clusters
+    if (wave == 0) {
+        int nids = 0, ca = 0, cb = 0;
+        for (long long c1 = 0; c1 < N; c1 += WAVE) {
+            const long long c = c1 + lane;
+            const bool alive_c = c < N && s_slot[c < N ? c : N - 1] >= 0;
+            const unsigned long long ma = __ballot(alive_c && c < sa), mb = __ballot(alive_c && c < sb);
+            ca += __popcll(ma); cb += __popcll(mb);
+            const bool take = alive_c && c != sa && c != sb;
+            const unsigned long long mk = __ballot(take);
+            if (take) s_ids[nids + __popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)c;
+            nids += __popcll(mk);
+        }
+        if (lane == 0) { s_cnt[0] = ca; s_cnt[1] = cb; }
+    }
+    // ---- M. the merged record, formed by every workgroup from the two old ones
+    {
+        const double* A0 = rec_quad(s_slot[sa]);
+        const double* B0 = rec_quad(s_slot[sb]);
+        for (int e = tid; e < QREC; e += STEP_TPB) ldsA[e] = A0[e] + B0[e];
+    }
+    __syncthreads();
+    const double nA = ldsA[QREC_COUNT_AT];
+    const int new_slot = (int)N + n_merges;
+    if (lead) {
+        // workgroup 0 keeps the books: the merged record in its fresh slot (both layouts),
+        // the slot word, the death mark, the merge log
+        double* Am = Q.exm + (off + n_merges) * QREC;
+        for (int e = tid; e < QREC; e += STEP_TPB) Am[e] = ldsA[e];
+        const double* Ap = rec_packed(s_slot[sa]);
+        const double* Bp = rec_packed(s_slot[sb]);
+        double* Pm = Q.pkm + (off + n_merges) * REC;
+        for (int e = tid; e < REC; e += STEP_TPB) Pm[e] = Ap[e] + Bp[e];
+        if (tid == 0) {
+            Q.sw[off + sa] = step_slot_word(k, new_slot, s_slot[sa]);
+            Q.death[off + sb] = k;
+            const int64_t o = off + n_merges;
+            out_a[o] = s_cnt[0]; out_b[o] = s_cnt[1]; out_d[o] = mind;
+        }
+    }
+    if (kind == SPKD_KL2 && wave == 0) {
+        double a[DA];
+        single_rows_from_qr(ldsA, a);
+        const double mean_i = a[D] / nA;
+        cov_rows(a, nA);
+        kl2_aux_from_cov(a, mean_i, s_auxA);
+        if (lead && lane < D) {
+            double* ga = aux + (off + sa) * AUX;
+            ga[lane] = s_auxA[lane]; ga[DA + lane] = s_auxA[DA + lane]; ga[2 * DA + lane] = s_auxA[2 * DA + lane];
+        }
+    }
+    // ---- P. this workgroup's items: item 0 = the merged cluster itself, item j >= 1 = partner
+    // s_ids[first + j - 1]
+    const int first = (int)blockIdx.x * STEP_PARTNERS;
+    const int mine_n = n_part - first < STEP_PARTNERS ? n_part - first : STEP_PARTNERS;   // partners here (>= 0)
+    if (kind != SPKD_KL2) {
+        const int base = 4 * wave;
+        if (base <= mine_n) {
+            int j = base + L.m;
+            const bool valid = j <= mine_n;
+            j = valid ? j : mine_n;
+            const int cslot = j == 0 ? s_slot[sa] : s_slot[s_ids[first + j - 1]];
+            // (the fallback's "global A" is the LDS copy: the merged record is not in global
+            // memory yet for anybody but workgroup 0)
+            const double v = quad_pair_det<TWO>(kind, ldsA, nA, ldsA, rec_quad(cslot), rec_packed(cslot), j == 0, L, err);
+            if (valid && L.t == 0) s_ldx[j] = v;
+        }
+    }
+    __syncthreads();
+    const double ldA = kind == SPKD_KL2 ? 0.0 : log(s_ldx[0]);
+    if (kind != SPKD_KL2 && lead && tid == 0) ldp[sa] = ldA;
+    // ---- finish the distances: a thread per partner; row sa (+ its staging copy), column sa
+    // (variant 1), the partner rows' caches into the other buffer
+    {
+        const int j = tid;
+        bool rescan = false;
+        double d = 0.0;
+        if (j >= 1 && j <= mine_n) {
+            const long long r = s_ids[first + j - 1];
+            if (kind == SPKD_KL2) {
+                const double* a2 = aux + (off + r) * AUX;
+                double t1 = 0.0, t2 = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    const float dm = (float)s_auxA[2 * DA + i] - (float)a2[2 * DA + i];
+                    const double delta = (double)dm;
+                    t1 += (s_auxA[i] - a2[i]) * (a2[DA + i] - s_auxA[DA + i]);
+                    t2 += ((s_auxA[DA + i] + a2[DA + i]) * delta) * delta;
+                }
+                d = 0.5 * t1 + 0.5 * t2;
+            } else {
+                const double nC = rec_packed(s_slot[r])[REC - 1];
+                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[r], log(s_ldx[j]));
+            }
+            double rm;
+            int ra, rn;
+            if (r == psa) { rm = s_psa.mv; ra = s_psa.mc; rn = s_psa.nc; }
+            else { rm = rmin_r[r]; ra = rarg_r[r]; rn = rnan_r[r]; }
+            Dm[sa * N + r] = d;
+            newrow_w[r] = d;
+            if (variant == 1) {
+                Dm[r * N + sa] = d;
+                const bool nan_hit = (rn == sa || rn == sb);
+                if (ra == sa || ra == sb || nan_hit) {
+                    if (!nan_hit && d < rm) { rm = d; ra = (int)sa; }    // still (or now) the strict row minimum
+                    else rescan = true;
+                } else if (d != d) {
+                    if ((int)sa < rn) rn = (int)sa;
+                } else if (d < rm || (d == rm && (int)sa < ra)) {
+                    rm = d; ra = (int)sa;
+                }
+            } else if (ra == sb || rn == sb) {       // column sa keeps its stale value (A-9)
+                rescan = true;
+            }
+            if (!rescan) { rmin_w[r] = rm; rarg_w[r] = ra; rnan_w[r] = rn; }
+        }
+        if (tid < 4 * STEP_WAVES) { s_rescan[tid] = rescan ? 1 : 0; s_dfin[tid] = d; }
+        __syncthreads();
+        for (int jj = 1 + wave; jj <= mine_n; jj += STEP_WAVES) {
+            if (!s_rescan[jj]) continue;             // (wave-uniform)
+            const long long r = s_ids[first + jj - 1];
+            double mv2;
+            int mc2, nc2;
+            step_scan_row(Dm + r * N, N, death, k, sb, variant == 1 ? sa : -1, s_dfin[jj], lane, mv2, mc2, nc2);
+            if (lane == 0) { rmin_w[r] = mv2; rarg_w[r] = mc2; rnan_w[r] = nc2; }
+        }
+    }
+    if (lead && tid == 0) {
+        StepState T;
+        T.done = 0; T.n_merges = n_merges + 1; T.psa = sa; T.fmin = mind;
+        *Snext = T;
+    }
+}
+
+// after the last round R: merge counts and the statistics of the final matrix
+__global__ __launch_bounds__(AHC_TPB) void k_step_final(
+        int last_round, const int64_t* __restrict__ seg_off, const double* __restrict__ mat,
+        const int64_t* __restrict__ mat_off, StepArrays Q, int32_t* __restrict__ out_n,
+        double* __restrict__ final_max, double* __restrict__ final_min) {
+    __shared__ double s_tmax[AHC_WAVES];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int p = blockIdx.x;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    const double* Dm = mat + mat_off[p];
+    const int32_t* death = Q.death + off;
+    const StepState S = Q.state2[(size_t)((last_round + 1) & 1) * Q.n_prob + p];
+    double tmax = -__builtin_huge_val();
+    bool anynan = false;
+    for (long long r = wave; r < N; r += AHC_WAVES) {
+        if (death[r] != ALIVE_ROUND) continue;
+        const double* row = Dm + r * N;
+        for (long long c = lane; c < N; c += WAVE) {
+            if (death[c] != ALIVE_ROUND) continue;
+            const double v = row[c];
+            if (v != v) anynan = true; else tmax = v > tmax ? v : tmax;
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < WAVE; s <<= 1) {
+        const double t2 = __shfl_xor(tmax, s);
+        tmax = t2 > tmax ? t2 : tmax;
+    }
+    anynan = __any(anynan);
+    if (lane == 0) s_tmax[wave] = anynan ? __builtin_nan("") : tmax;
+    __syncthreads();
+    if (tid == 0) {
+        double mx = s_tmax[0];
+        for (int w = 1; w < AHC_WAVES; ++w) {
+            const double x = s_tmax[w];
+            if (mx == mx) mx = (x != x) ? x : (x > mx ? x : mx);
+        }
+        out_n[p] = S.n_merges;
+        final_max[p] = mx;
+        final_min[p] = S.fmin;
+    }
+}
+
 }  // namespace spkd

@@ -21,7 +21,7 @@
 using namespace spkd;
 
 namespace {
-constexpr int N_SLOTS = 28;
+constexpr int N_SLOTS = 32;
 }
 
 struct spkd_ctx {
@@ -31,6 +31,7 @@ struct spkd_ctx {
     bool gw_lds_ok = false;
     int gw_waves = 0;
     unsigned long long init_keys[2] = {0ull, ~0ull};
+    int ahc_chain = 0;           // wide merge loop: 0 / 2 = the step chain (no hand-offs), 1 = the ticket chain
     int64_t last_gw_items = 0;
     std::string err;
     int* d_err = nullptr;
@@ -125,8 +126,10 @@ spkd_status end_call(spkd_ctx* c) {
 enum {
     S_CHUNKS = 0, S_SETOFF, S_PARTIAL, S_IDXA, S_IDXB, S_TERMS, S_TURNS, S_SNAP, S_CAND,
     S_EV_I32A, S_EV_I32B, S_EV_D0, S_EV_D1, S_EV_D2, S_EV_D3, S_EV_D4, S_LOG,
-    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB, S_AHC_PACKED, S_MFCC_TAB, S_MFCC_STATIC
+    S_AHC_STATS, S_AHC_LD, S_AHC_AUX, S_AHC_MAT, S_AHC_MISC, S_AHC_OUT, S_AHC_OFF, S_AHC_PROB, S_AHC_PACKED, S_MFCC_TAB, S_MFCC_STATIC,
+    S_STEP_EXM, S_STEP_PKM, S_STEP_MISC, S_COUNT
 };
+static_assert(S_COUNT <= N_SLOTS, "scratch slot table too small");
 
 }  // namespace
 
@@ -171,6 +174,7 @@ static spkd_status create_ctx(int device, void* stream, bool borrow, spkd_ctx** 
                    hipFuncSetAttribute((const void*)k_gw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<1>::LDS_BYTES) == hipSuccess;
     // waves per turn of the growing-window kernel: 0 = by the number of turns (gw_impl)
     if (const char* e = getenv("SPKD_GW_WAVES")) c->gw_waves = atoi(e);
+    if (const char* e = getenv("SPKD_AHC_CHAIN")) c->ahc_chain = atoi(e);
     *out = c;
     return SPKD_OK;
 }
@@ -599,6 +603,47 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
                                  B.ex, B.pk, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                                  P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, d_alive, d_tmp,
                                  d_rmin, d_rcache, d_n, d_a, d_b, d_merge_d, B.smax, B.smin, d_fmax, d_fmin, c->d_err));
+    } else if (c->ahc_chain != 1 && n_max <= STEP_MAX_N) {
+        // the step chain: one launch per merge, every workgroup selects for itself (spkd_cluster.hpp)
+        StepArrays Q;
+        void *pm = nullptr, *pe = nullptr, *pp = nullptr;
+        const size_t nt = (size_t)n_total;
+        const size_t misc_bytes = nt * (2 + 2) * sizeof(double) + nt * sizeof(unsigned long long) +
+                                  (size_t)2 * n_prob * sizeof(StepState) + nt * 5 * sizeof(int32_t) + 64;
+        if ((st = scratch(c, S_STEP_MISC, misc_bytes, &pm)) != SPKD_OK) return st;
+        if ((st = scratch(c, S_STEP_EXM, nt * QREC * sizeof(double), &pe)) != SPKD_OK) return st;
+        if ((st = scratch(c, S_STEP_PKM, nt * REC * sizeof(double), &pp)) != SPKD_OK) return st;
+        Q.ex = B.ex; Q.pk = B.pk; Q.exm = (double*)pe; Q.pkm = (double*)pp;
+        Q.rmin2 = (double*)pm;
+        Q.newrow2 = Q.rmin2 + 2 * nt;
+        Q.sw = (unsigned long long*)(Q.newrow2 + 2 * nt);
+        Q.state2 = (StepState*)(Q.sw + nt);
+        Q.death = (int32_t*)(Q.state2 + 2 * n_prob);
+        Q.rarg2 = Q.death + nt;
+        Q.rnan2 = Q.rarg2 + 2 * nt;
+        Q.n_total = n_total;
+        Q.n_prob = (int32_t)n_prob;
+        auto kstep = P->kind == SPKD_GLR ? k_ahc_step<true> : k_ahc_step<false>;
+        const size_t step_lds = (size_t)2 * n_max * sizeof(int32_t);
+        if (step_lds + 20 * 1024 > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)kstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
+        (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
+        const unsigned row_blocks = (unsigned)((n_max + AHC_WAVES - 1) / AHC_WAVES);
+        hipLaunchKernelGGL(k_step_init, dim3(row_blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                           (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off, Q);
+        for (int64_t it = 1; it < n_max; ++it) {
+            const int64_t partners = n_max - it - 1;
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + STEP_PARTNERS - 1) / STEP_PARTNERS);
+            hipLaunchKernelGGL(kstep, dim3(blocks, (unsigned)n_prob), dim3(STEP_TPB), step_lds, c->stream,
+                               (int)it, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
+                               P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, Q, d_a, d_b, d_merge_d,
+                               B.smax, B.smin, c->d_err);
+        }
+        hipLaunchKernelGGL(k_step_final, dim3((unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
+                           (int)(n_max - 1), (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off,
+                           Q, d_n, d_fmax, d_fmin);
+        (void)hipEventRecord(c->kb[SPKD_T_AHC], c->stream);
+        c->kused[SPKD_T_AHC] = true;
     } else {
         auto kround = P->kind == SPKD_GLR ? k_ahc_round<true> : k_ahc_round<false>;
         (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
