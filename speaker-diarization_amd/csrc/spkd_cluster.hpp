@@ -1478,6 +1478,9 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     if ((int)blockIdx.x >= nb) return;
     int32_t* s_ids = s_dyn;
     int32_t* s_slot = s_dyn + N;
+    const int nch = (int)((N + WAVE - 1) / WAVE);    // 64-cluster chunks: alive masks and their running counts
+    int32_t* s_base = s_dyn + 2 * N;
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_dyn + ((2 * N + nch + 1) & ~1LL));
     const int rb = k & 1, wb = (k + 1) & 1;
     const int32_t* death = Q.death + off;
     const double* rmin_r = Q.rmin2 + (size_t)rb * Q.n_total + off;
@@ -1505,7 +1508,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     int mc = NO_COL, nc = NO_COL;
     ArgMin mine;
     mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
-#pragma unroll 2
+#pragma unroll 4
     for (long long x = tid; x < N; x += STEP_TPB) {
         const int dth = death[x];
         const unsigned long long w = Q.sw[off + x];
@@ -1514,6 +1517,10 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         const int c = rarg_r[x], rn = rnan_r[x];
         const bool a = dth >= k;
         s_slot[x] = a ? step_slot_of(w, k) : -1;
+        {   // (a wave's lanes hold 64 consecutive clusters: chunk x / 64)
+            const unsigned long long mk = __ballot(a);
+            if (lane == 0) s_mask[x >> 6] = mk;
+        }
         if (!a) continue;
         if (psa >= 0) {
             const double d = x == psa ? diag_psa : dn;
@@ -1591,22 +1598,35 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         return;
     }
     const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
-    // ---- partner list, in ascending slot order (the same in every workgroup), and the merge's
-    // compacted indices = alive slots in front: wave 0, a ballot per 64 clusters
+    // ---- partner list, in ascending slot order (the same in every workgroup): the alive rank of
+    // a cluster = the running count of its chunk + the alive lanes in front of it; the merge's
+    // compacted indices are the alive ranks of sa and sb; a partner's place in the list is its
+    // alive rank less the merged pair in front of it.  (One wave scans the chunk counts, every
+    // thread places its clusters: no loop over the clusters by a single wave.)
     if (wave == 0) {
-        int nids = 0, ca = 0, cb = 0;
-        for (long long c1 = 0; c1 < N; c1 += WAVE) {
-            const long long c = c1 + lane;
-            const bool alive_c = c < N && s_slot[c < N ? c : N - 1] >= 0;
-            const unsigned long long ma = __ballot(alive_c && c < sa), mb = __ballot(alive_c && c < sb);
-            ca += __popcll(ma); cb += __popcll(mb);
-            const bool take = alive_c && c != sa && c != sb;
-            const unsigned long long mk = __ballot(take);
-            if (take) s_ids[nids + __popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)c;
-            nids += __popcll(mk);
+        int run = 0;
+        for (int c1 = 0; c1 < nch; c1 += WAVE) {
+            const int ch = c1 + lane;
+            const int cnt = ch < nch ? __popcll(s_mask[ch]) : 0;
+            int inc = cnt;
+#pragma unroll
+            for (int sft = 1; sft < WAVE; sft <<= 1) {
+                const int up = __shfl_up(inc, sft);
+                if (lane >= sft) inc += up;
+            }
+            if (ch < nch) s_base[ch] = run + inc - cnt;
+            run += __shfl(inc, WAVE - 1);
         }
-        if (lane == 0) { s_cnt[0] = ca; s_cnt[1] = cb; }
     }
+    __syncthreads();
+    const int ca = s_base[sa >> 6] + __popcll(s_mask[sa >> 6] & ((1ull << (sa & 63)) - 1ull));
+    const int cb = s_base[sb >> 6] + __popcll(s_mask[sb >> 6] & ((1ull << (sb & 63)) - 1ull));
+    for (long long x = tid; x < N; x += STEP_TPB) {
+        if (s_slot[x] < 0 || x == sa || x == sb) continue;
+        const int ar = s_base[x >> 6] + __popcll(s_mask[x >> 6] & ((1ull << (x & 63)) - 1ull));
+        s_ids[ar - (ar > ca ? 1 : 0) - (ar > cb ? 1 : 0)] = (int32_t)x;
+    }
+    if (tid == 0) { s_cnt[0] = ca; s_cnt[1] = cb; }
     // ---- M. the merged record, formed by every workgroup from the two old ones
     {
         const double* A0 = rec_quad(s_slot[sa]);

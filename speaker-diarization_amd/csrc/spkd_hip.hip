@@ -624,7 +624,8 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         Q.n_total = n_total;
         Q.n_prob = (int32_t)n_prob;
         auto kstep = P->kind == SPKD_GLR ? k_ahc_step<true> : k_ahc_step<false>;
-        const size_t step_lds = (size_t)2 * n_max * sizeof(int32_t);
+        const size_t nch_max = (size_t)((n_max + WAVE - 1) / WAVE);
+        const size_t step_lds = ((size_t)2 * n_max + nch_max + 2) * sizeof(int32_t) + nch_max * sizeof(unsigned long long);
         if (step_lds + 20 * 1024 > 48 * 1024)
             (void)hipFuncSetAttribute((const void*)kstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
         (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
