@@ -55,7 +55,7 @@ REC_BYTES = 6560
 FLOP_PER_DET = 2 * (9880 + 780 + 780)
 FLOP_PER_FRAME = 2 * 820
 FP64_PEAK_TFLOPS = 78.6
-TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r02_bench256_hbm_traffic.json')
+TRAFFIC_PROFILE = os.path.join(ROOT, 'profiles', 'r03_bench256_hbm_traffic.json')
 
 CD_ARGS = ['-m', 'gw', '-d', 'BIC', '-w', '1.0', '-st', '3.0', '-dws', '0.1', '-l', '1.0']
 CL_ARGS = ['-m', 'hi', '-l', '1.3']
