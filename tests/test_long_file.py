@@ -92,3 +92,60 @@ def test_two_ranks_equal_one_rank_equal_the_batch_pipeline(tmp_path):
     assert np.array_equal(a['stat'], b['stat'])
     print(r2.stdout.strip().splitlines()[-1])
     print(r1.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant,kind,threshold', [(2, 'BIC', 0.0), (1, 'GLR', 1500.0), (2, 'KL2', 30.0)])
+def test_row_blocks_and_supplied_matrix_equal_spkd_ahc(variant, kind, threshold):
+    """The two halves a long file is tiled with -- spkd_distance_rows over three row blocks
+    (assembled as the ranks would) and spkd_ahc_matrix on the result -- against spkd_ahc on
+    the same records, for the other variant and the other distances: merge log, distance
+    statistics and the assembled matrix itself bit for bit (spk-clustering2.py:173-222 for
+    variant 2: lower triangle +inf, the merge loop rewrites rows only)."""
+    hipabi = importlib.import_module('speaker-diarization_amd.hipabi')
+    synth = importlib.import_module('speaker-diarization_amd.synth')
+    feats, vad, truth = synth.make_session(4242, 150, 3)
+    segs = [(s, e) for (s, e, _) in truth]
+    n = len(segs)
+    ctx = hipabi.Context(0)
+    try:
+        d_fr = ctx.dev_alloc(feats.nbytes)
+        ctx.h2d(d_fr, feats)
+        d_st = ctx.dev_alloc(n * hipabi.REC * 8)
+        ctx.set_stats(d_fr, feats.shape[0], [s for s, _ in segs], [e for _, e in segs], np.arange(n, dtype=np.int32), n, d_st)
+        p = hipabi.AhcParams(variant, hipabi.KINDS[kind], 0, hipabi.AHC_WIDE, 1.3, threshold)
+        ref = ctx.ahc(d_st, [0, n], p)
+        blocks = dmod.row_blocks(n, 3)
+        full = np.empty((n, n), dtype=np.float64)
+        smax, smin = [], []
+        for rb, re_ in blocks:
+            d_rows = ctx.dev_alloc(max(re_ - rb, 1) * n * 8)
+            a, b = ctx.distance_rows(variant, kind, 1.3, d_st, n, rb, re_, d_rows)
+            part = np.empty((re_ - rb, n), dtype=np.float64)
+            if re_ > rb:
+                ctx.d2h(part, d_rows)
+            full[rb:re_] = part
+            ctx.dev_free(d_rows)
+            smax.append(a); smin.append(b)
+        if variant == 1:
+            up = np.triu(full, 1)
+            full = up + up.T
+            np.fill_diagonal(full, 9223372036854775808.0)
+        d_whole = ctx.dev_alloc(n * n * 8)
+        ctx.distance_rows(variant, kind, 1.3, d_st, n, 0, n, d_whole)
+        whole = np.empty((n, n), dtype=np.float64)
+        ctx.d2h(whole, d_whole)
+        assert np.array_equal(full, whole, equal_nan=True)           # blocks assembled == one block
+        d_m = ctx.dev_alloc(n * n * 8)
+        ctx.h2d(d_m, np.ascontiguousarray(full))
+        fmax = np.nanmax(smax) if np.any(np.array(smax) == np.array(smax)) else float('nan')
+        fmin = np.nanmin(smin) if np.any(np.array(smin) == np.array(smin)) else float('nan')
+        got = ctx.ahc_matrix(d_st, n, p, d_m, fmax, fmin)
+        nm = int(ref['n_merges'][0])
+        assert nm > 5 and int(got['n_merges'][0]) == nm
+        for k in ('a', 'b', 'd'):
+            assert np.array_equal(ref[k][:nm], got[k][:nm], equal_nan=True), k
+        assert np.array_equal(ref['stat_max'], got['stat_max'], equal_nan=True)
+        assert np.array_equal(ref['stat_min'], got['stat_min'], equal_nan=True)
+    finally:
+        ctx.close()
