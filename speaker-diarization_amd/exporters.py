@@ -97,7 +97,13 @@ def _xml_text(v):
 
 def write_elan(recipe, outf, date=None):
     """ELAN document of a recipe: two time slots per line (milliseconds, truncated) and one
-    alignable annotation per line on a single `Speakers` tier (aku2elan.py:45-99)."""
+    alignable annotation per line on a single `Speakers` tier (aku2elan.py:45-99).
+    PARITY UNPINNED (the reference writes through lxml, which is not importable here, and no
+    golden `.eaf` exists).  Known deviations from what lxml would emit: a media file whose
+    type `mimetypes.guess_type` does not know gets MIME_TYPE="" here, where the reference
+    hands lxml a None and fails; attribute values are escaped by `_xml_attr` (&, <, >, ")
+    rather than by lxml's serialiser (which also writes ' as-is and numeric character
+    references for non-ASCII text under its default ASCII encoding)."""
     from mimetypes import guess_type
 
     def tag(indent, name, attrs, text=None, close=True):
