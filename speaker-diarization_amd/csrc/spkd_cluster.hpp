@@ -267,8 +267,11 @@ __device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, do
                                                    const double* __restrict__ gA,
                                                    const double* __restrict__ qrC,
                                                    const double* __restrict__ pkC, bool self,
-                                                   const QuadLane& L, int* err) {
-    const double nC = self ? 0.0 : pkC[REC - 1];
+                                                   const QuadLane& L, int* err, double nC_known = -1.0) {
+    // (nC_known >= 0: the caller has the partner's frame count already -- the step chain keeps
+    // the counts in an array of their own, so that a pass does not wait for the count before it
+    // can issue its 81 record loads: two memory round trips in a row on the chain's critical path)
+    const double nC = self ? 0.0 : (nC_known >= 0.0 ? nC_known : pkC[REC - 1]);
     const double n = nA + nC;
     const bool glr = TWO && (kind == SPKD_GLR && !self);
     // (an IEEE fp64 division is ~25 instructions; the covariance scale uses the Newton
@@ -1366,6 +1369,7 @@ struct StepArrays {
     int32_t* rnan2;          // [2][n_total]
     double* newrow2;         // [2][n_total]
     unsigned long long* sw;  // [n_total]
+    double* cnt;             // [n_total] frame count of every cluster (a merged one: written by its round)
     StepState* state2;       // [2][n_prob]
     int64_t n_total;
     int32_t n_prob;
@@ -1397,6 +1401,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_step_init(
         Q.rnan2[Q.n_total + off + r] = nc;
         Q.death[off + r] = ALIVE_ROUND;
         Q.sw[off + r] = step_slot_word(0, (int)r, (int)r);
+        Q.cnt[off + r] = Q.pk[(off + r) * REC + REC - 1];
     }
 }
 
@@ -1461,6 +1466,13 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
     const int p = blockIdx.y;
+#ifdef SPKD_PROFILE
+    // profiling builds: phase clocks of thread 0 of workgroup 0 (tools/step_phase_profile.py)
+    unsigned long long st_t = clock64();
+#define STEP_TICK(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_ahc_prof[i], now_ - st_t); st_t = now_; } while (0)
+#else
+#define STEP_TICK(i) ((void)0)
+#endif
     const StepState S = Q.state2[(size_t)(k & 1) * Q.n_prob + p];
     StepState* Snext = Q.state2 + (size_t)((k + 1) & 1) * Q.n_prob + p;
     const bool lead = blockIdx.x == 0;
@@ -1475,7 +1487,12 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     const long long m = N - n_merges;                // clusters alive now
     const int n_part = (int)(m - 2);                 // partners of this merge, if it happens
     const int nb = n_part > 0 ? (n_part + STEP_PARTNERS - 1) / STEP_PARTNERS : 1;
-    if ((int)blockIdx.x >= nb) return;
+    // workgroups 0 .. nb - 1 take the partners; workgroup nb is the BOOKKEEPER: it selects like
+    // everybody, forms the merged record, and writes it out (both layouts), the slot word, the
+    // count, the death mark and the merge log while the others eliminate -- 5 k cycles that sat
+    // on the critical path of workgroup 0 (tools/step_phase_profile.py)
+    if ((int)blockIdx.x > nb) return;
+    const bool keeper = (int)blockIdx.x == nb;
     int32_t* s_ids = s_dyn;
     int32_t* s_slot = s_dyn + N;
     const int nch = (int)((N + WAVE - 1) / WAVE);    // 64-cluster chunks: alive masks and their running counts
@@ -1508,34 +1525,52 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     int mc = NO_COL, nc = NO_COL;
     ArgMin mine;
     mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
-#pragma unroll 4
-    for (long long x = tid; x < N; x += STEP_TPB) {
-        const int dth = death[x];
-        const unsigned long long w = Q.sw[off + x];
-        const double dn = newrow_r[x];
-        const double v = rmin_r[x];
-        const int c = rarg_r[x], rn = rnan_r[x];
-        const bool a = dth >= k;
-        s_slot[x] = a ? step_slot_of(w, k) : -1;
-        {   // (a wave's lanes hold 64 consecutive clusters: chunk x / 64)
+    // (eight clusters per thread at a time, all their loads in flight before the first is looked
+    // at: a wave's lanes hold 64 consecutive clusters, chunk x / 64)
+    constexpr int SEL_U = 8;
+    for (long long x0 = tid; x0 < N; x0 += (long long)SEL_U * STEP_TPB) {
+        int dth[SEL_U], c_[SEL_U], rn_[SEL_U];
+        unsigned long long w_[SEL_U];
+        double dn_[SEL_U], v_[SEL_U];
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const long long x = x0 + (long long)u * STEP_TPB;
+            const long long xc = x < N ? x : N - 1;
+            dth[u] = death[xc];
+            w_[u] = Q.sw[off + xc];
+            dn_[u] = newrow_r[xc];
+            v_[u] = rmin_r[xc];
+            c_[u] = rarg_r[xc];
+            rn_[u] = rnan_r[xc];
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const long long x = x0 + (long long)u * STEP_TPB;
+            const bool in = x < N;                     // (uniform per wave: a wave covers one chunk)
+            const bool a = in && dth[u] >= k;
             const unsigned long long mk = __ballot(a);
-            if (lane == 0) s_mask[x >> 6] = mk;
-        }
-        if (!a) continue;
-        if (psa >= 0) {
-            const double d = x == psa ? diag_psa : dn;
-            if (variant == 1 && x != psa && stat_valid(d)) {
-                wmax = (wmax != wmax || d > wmax) ? d : wmax;
-                wmin = (wmin != wmin || d < wmin) ? d : wmin;
+            if (in) {
+                s_slot[x] = a ? step_slot_of(w_[u], k) : -1;
+                if (lane == 0) s_mask[x >> 6] = mk;
             }
-            if (d != d) { if ((int)x < nc) nc = (int)x; }
-            else if (d < mv || (d == mv && (int)x < mc)) { mv = d; mc = (int)x; }
-        }
-        if (x != psa) {
-            if (rn != NO_COL) { const long long l = x * N + rn; if (l < mine.nan_idx) mine.nan_idx = l; }
-            if (c != NO_COL) {
-                const long long l = x * N + c;
-                if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+            if (!a) continue;
+            const double v = v_[u];
+            const int c = c_[u], rn = rn_[u];
+            if (psa >= 0) {
+                const double d = x == psa ? diag_psa : dn_[u];
+                if (variant == 1 && x != psa && stat_valid(d)) {
+                    wmax = (wmax != wmax || d > wmax) ? d : wmax;
+                    wmin = (wmin != wmin || d < wmin) ? d : wmin;
+                }
+                if (d != d) { if ((int)x < nc) nc = (int)x; }
+                else if (d < mv || (d == mv && (int)x < mc)) { mv = d; mc = (int)x; }
+            }
+            if (x != psa) {
+                if (rn != NO_COL) { const long long l = x * N + rn; if (l < mine.nan_idx) mine.nan_idx = l; }
+                if (c != NO_COL) {
+                    const long long l = x * N + c;
+                    if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+                }
             }
         }
     }
@@ -1583,6 +1618,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         best = b;
     }
     __syncthreads();
+    STEP_TICK(2);                                    // selection: one pass + reductions
     const bool has_nan = best.nan_idx != INF_IDX;
     const double mind = has_nan ? __builtin_nan("") : best.v;
     const long long index = has_nan ? best.nan_idx : best.idx;
@@ -1598,6 +1634,20 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         return;
     }
     const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
+    // ---- M (first half). the two old records of the merged pair on their way to registers
+    // while the partner list is being built
+    constexpr int M_PER = (QREC + STEP_TPB - 1) / STEP_TPB;
+    double m_a[M_PER], m_b[M_PER];
+    {
+        const double* A0 = rec_quad(s_slot[sa]);
+        const double* B0 = rec_quad(s_slot[sb]);
+#pragma unroll
+        for (int u = 0; u < M_PER; ++u) {
+            const int e = tid + u * STEP_TPB;
+            m_a[u] = A0[e < QREC ? e : 0];
+            m_b[u] = B0[e < QREC ? e : 0];
+        }
+    }
     // ---- partner list, in ascending slot order (the same in every workgroup): the alive rank of
     // a cluster = the running count of its chunk + the alive lanes in front of it; the merge's
     // compacted indices are the alive ranks of sa and sb; a partner's place in the list is its
@@ -1627,18 +1677,19 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         s_ids[ar - (ar > ca ? 1 : 0) - (ar > cb ? 1 : 0)] = (int32_t)x;
     }
     if (tid == 0) { s_cnt[0] = ca; s_cnt[1] = cb; }
-    // ---- M. the merged record, formed by every workgroup from the two old ones
-    {
-        const double* A0 = rec_quad(s_slot[sa]);
-        const double* B0 = rec_quad(s_slot[sb]);
-        for (int e = tid; e < QREC; e += STEP_TPB) ldsA[e] = A0[e] + B0[e];
+    // ---- M (second half). the merged record, formed by every workgroup from the two old ones
+#pragma unroll
+    for (int u = 0; u < M_PER; ++u) {
+        const int e = tid + u * STEP_TPB;
+        if (e < QREC) ldsA[e] = m_a[u] + m_b[u];
     }
     __syncthreads();
+    STEP_TICK(3);                                    // partner list + merged record
     const double nA = ldsA[QREC_COUNT_AT];
     const int new_slot = (int)N + n_merges;
-    if (lead) {
-        // workgroup 0 keeps the books: the merged record in its fresh slot (both layouts),
-        // the slot word, the death mark, the merge log
+    if (keeper) {
+        // the books: the merged record in its fresh slot (both layouts), the slot word, the
+        // count, the death mark, the merge log
         double* Am = Q.exm + (off + n_merges) * QREC;
         for (int e = tid; e < QREC; e += STEP_TPB) Am[e] = ldsA[e];
         const double* Ap = rec_packed(s_slot[sa]);
@@ -1647,6 +1698,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         for (int e = tid; e < REC; e += STEP_TPB) Pm[e] = Ap[e] + Bp[e];
         if (tid == 0) {
             Q.sw[off + sa] = step_slot_word(k, new_slot, s_slot[sa]);
+            Q.cnt[off + sa] = nA;                    // (read by later rounds only: sa is nobody's partner now)
             Q.death[off + sb] = k;
             const int64_t o = off + n_merges;
             out_a[o] = s_cnt[0]; out_b[o] = s_cnt[1]; out_d[o] = mind;
@@ -1658,11 +1710,13 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         const double mean_i = a[D] / nA;
         cov_rows(a, nA);
         kl2_aux_from_cov(a, mean_i, s_auxA);
-        if (lead && lane < D) {
+        if (keeper && lane < D) {
             double* ga = aux + (off + sa) * AUX;
             ga[lane] = s_auxA[lane]; ga[DA + lane] = s_auxA[DA + lane]; ga[2 * DA + lane] = s_auxA[2 * DA + lane];
         }
     }
+    if (keeper) return;
+    STEP_TICK(4);
     // ---- P. this workgroup's items: item 0 = the merged cluster itself, item j >= 1 = partner
     // s_ids[first + j - 1]
     const int first = (int)blockIdx.x * STEP_PARTNERS;
@@ -1673,15 +1727,21 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
             int j = base + L.m;
             const bool valid = j <= mine_n;
             j = valid ? j : mine_n;
-            const int cslot = j == 0 ? s_slot[sa] : s_slot[s_ids[first + j - 1]];
+            const long long cx = j == 0 ? sa : (long long)s_ids[first + j - 1];
+            const int cslot = s_slot[cx];
+            const double nCx = j == 0 ? 0.0 : Q.cnt[off + cx];
             // (the fallback's "global A" is the LDS copy: the merged record is not in global
             // memory yet for anybody but workgroup 0)
-            const double v = quad_pair_det<TWO>(kind, ldsA, nA, ldsA, rec_quad(cslot), rec_packed(cslot), j == 0, L, err);
+            const double v = quad_pair_det<TWO>(kind, ldsA, nA, ldsA, rec_quad(cslot), rec_packed(cslot), j == 0, L, err, nCx);
             if (valid && L.t == 0) s_ldx[j] = v;
         }
     }
     __syncthreads();
-    const double ldA = kind == SPKD_KL2 ? 0.0 : log(s_ldx[0]);
+    STEP_TICK(5);                                    // the pass
+    // the logs of the 16 determinants side by side (the merged cluster's own term among them)
+    if (kind != SPKD_KL2 && tid <= mine_n) s_ldx[tid] = log(s_ldx[tid]);
+    __syncthreads();
+    const double ldA = kind == SPKD_KL2 ? 0.0 : s_ldx[0];
     if (kind != SPKD_KL2 && lead && tid == 0) ldp[sa] = ldA;
     // ---- finish the distances: a thread per partner; row sa (+ its staging copy), column sa
     // (variant 1), the partner rows' caches into the other buffer
@@ -1702,8 +1762,8 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
                 }
                 d = 0.5 * t1 + 0.5 * t2;
             } else {
-                const double nC = rec_packed(s_slot[r])[REC - 1];
-                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[r], log(s_ldx[j]));
+                const double nC = Q.cnt[off + r];
+                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[r], s_ldx[j]);
             }
             double rm;
             int ra, rn;
@@ -1738,6 +1798,10 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
             if (lane == 0) { rmin_w[r] = mv2; rarg_w[r] = mc2; rnan_w[r] = nc2; }
         }
     }
+    STEP_TICK(6);                                    // logs, distances, row caches, rescans
+#ifdef SPKD_PROFILE
+    if (lead && tid == 0) atomicAdd(&g_ahc_prof[1], 1ull);
+#endif
     if (lead && tid == 0) {
         StepState T;
         T.done = 0; T.n_merges = n_merges + 1; T.psa = sa; T.fmin = mind;

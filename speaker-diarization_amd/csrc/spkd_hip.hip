@@ -608,7 +608,7 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         StepArrays Q;
         void *pm = nullptr, *pe = nullptr, *pp = nullptr;
         const size_t nt = (size_t)n_total;
-        const size_t misc_bytes = nt * (2 + 2) * sizeof(double) + nt * sizeof(unsigned long long) +
+        const size_t misc_bytes = nt * (2 + 2 + 1) * sizeof(double) + nt * sizeof(unsigned long long) +
                                   (size_t)2 * n_prob * sizeof(StepState) + nt * 5 * sizeof(int32_t) + 64;
         if ((st = scratch(c, S_STEP_MISC, misc_bytes, &pm)) != SPKD_OK) return st;
         if ((st = scratch(c, S_STEP_EXM, nt * QREC * sizeof(double), &pe)) != SPKD_OK) return st;
@@ -616,7 +616,8 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         Q.ex = B.ex; Q.pk = B.pk; Q.exm = (double*)pe; Q.pkm = (double*)pp;
         Q.rmin2 = (double*)pm;
         Q.newrow2 = Q.rmin2 + 2 * nt;
-        Q.sw = (unsigned long long*)(Q.newrow2 + 2 * nt);
+        Q.cnt = Q.newrow2 + 2 * nt;
+        Q.sw = (unsigned long long*)(Q.cnt + nt);
         Q.state2 = (StepState*)(Q.sw + nt);
         Q.death = (int32_t*)(Q.state2 + 2 * n_prob);
         Q.rarg2 = Q.death + nt;
@@ -634,7 +635,8 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
                            (const int64_t*)B.seg_off, (const double*)B.mat, (const int64_t*)B.mat_off, Q);
         for (int64_t it = 1; it < n_max; ++it) {
             const int64_t partners = n_max - it - 1;
-            const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + STEP_PARTNERS - 1) / STEP_PARTNERS);
+            // (+ 1: the bookkeeper workgroup of every problem)
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + STEP_PARTNERS - 1) / STEP_PARTNERS) + 1;
             hipLaunchKernelGGL(kstep, dim3(blocks, (unsigned)n_prob), dim3(STEP_TPB), step_lds, c->stream,
                                (int)it, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                                P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, Q, d_a, d_b, d_merge_d,
