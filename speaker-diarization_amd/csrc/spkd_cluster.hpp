@@ -1358,16 +1358,22 @@ __device__ __forceinline__ int step_slot_of(unsigned long long w, int k) {
     return ((int)(w >> 40) < k) ? (int)((w >> 20) & 0xfffffull) : (int)(w & 0xfffffull);
 }
 
+// what the selection reads per cluster, one 32-byte line piece per round parity: the row cache
+// (minimum, its first column, first NaN column), the cluster's entry of the newest matrix row
+// (written in round k for the selection of round k + 1: the same parity as the caches), and
+// the round the cluster died in (kept in BOTH parities; ALIVE_ROUND while alive)
+struct StepSel {
+    double rmin, newrow;
+    int32_t rarg, rnan, death, pad;
+};
+
 struct StepArrays {
     double* ex;              // initial records, quad layout (slots 0 .. N - 1 of a problem)
     double* pk;              //                  packed
     double* exm;             // merged records (slot N + m of a problem = record off + m here)
     double* pkm;
-    int32_t* death;
-    double* rmin2;           // [2][n_total]
-    int32_t* rarg2;          // [2][n_total]
-    int32_t* rnan2;          // [2][n_total]
-    double* newrow2;         // [2][n_total]
+    int32_t* death;          // [n_total] (the row rescans and the final statistics read this copy)
+    StepSel* sel2;           // [2][n_total]
     unsigned long long* sw;  // [n_total]
     double* cnt;             // [n_total] frame count of every cluster (a merged one: written by its round)
     StepState* state2;       // [2][n_prob]
@@ -1396,9 +1402,10 @@ __global__ __launch_bounds__(AHC_TPB) void k_step_init(
     int mc, nc;
     ahc_scan_row(mat + mat_off[p] + r * N, N, nullptr, true, -1, 0.0, lane, mv, mc, nc);
     if (lane == 0) {
-        Q.rmin2[Q.n_total + off + r] = mv;
-        Q.rarg2[Q.n_total + off + r] = mc;
-        Q.rnan2[Q.n_total + off + r] = nc;
+        StepSel e;
+        e.rmin = mv; e.newrow = 0.0; e.rarg = mc; e.rnan = nc; e.death = ALIVE_ROUND; e.pad = 0;
+        Q.sel2[Q.n_total + off + r] = e;
+        Q.sel2[off + r] = e;
         Q.death[off + r] = ALIVE_ROUND;
         Q.sw[off + r] = step_slot_word(0, (int)r, (int)r);
         Q.cnt[off + r] = Q.pk[(off + r) * REC + REC - 1];
@@ -1500,14 +1507,8 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(s_dyn + ((2 * N + nch + 1) & ~1LL));
     const int rb = k & 1, wb = (k + 1) & 1;
     const int32_t* death = Q.death + off;
-    const double* rmin_r = Q.rmin2 + (size_t)rb * Q.n_total + off;
-    const int32_t* rarg_r = Q.rarg2 + (size_t)rb * Q.n_total + off;
-    const int32_t* rnan_r = Q.rnan2 + (size_t)rb * Q.n_total + off;
-    double* rmin_w = Q.rmin2 + (size_t)wb * Q.n_total + off;
-    int32_t* rarg_w = Q.rarg2 + (size_t)wb * Q.n_total + off;
-    int32_t* rnan_w = Q.rnan2 + (size_t)wb * Q.n_total + off;
-    const double* newrow_r = Q.newrow2 + (size_t)((k - 1) & 1) * Q.n_total + off;
-    double* newrow_w = Q.newrow2 + (size_t)(k & 1) * Q.n_total + off;
+    const StepSel* sel_r = Q.sel2 + (size_t)rb * Q.n_total + off;
+    StepSel* sel_w = Q.sel2 + (size_t)wb * Q.n_total + off;
     double* Dm = mat + mat_off[p];
     double* ldp = ld + off;
     const long long INF_IDX = 0x7fffffffffffffffLL;
@@ -1523,8 +1524,11 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     const double diag_psa = psa >= 0 ? Dm[psa * N + psa] : 0.0;
     double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
     int mc = NO_COL, nc = NO_COL;
-    ArgMin mine;
-    mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+    // (a thread meets its clusters in ascending order, so "the smaller linear index on a tie" is
+    // "the one met first": the running best is kept as (value, row, column) in ints, the NaN
+    // index as the first row that has one -- no 64-bit index arithmetic per cluster)
+    double bv = __builtin_huge_val();
+    int bx = -1, bc = 0, nx = -1, ncol = 0;
     // (eight clusters per thread at a time, all their loads in flight before the first is looked
     // at: a wave's lanes hold 64 consecutive clusters, chunk x / 64)
     constexpr int SEL_U = 8;
@@ -1536,12 +1540,9 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         for (int u = 0; u < SEL_U; ++u) {
             const long long x = x0 + (long long)u * STEP_TPB;
             const long long xc = x < N ? x : N - 1;
-            dth[u] = death[xc];
+            const StepSel e = sel_r[xc];                  // (two 16-byte loads)
             w_[u] = Q.sw[off + xc];
-            dn_[u] = newrow_r[xc];
-            v_[u] = rmin_r[xc];
-            c_[u] = rarg_r[xc];
-            rn_[u] = rnan_r[xc];
+            dth[u] = e.death; dn_[u] = e.newrow; v_[u] = e.rmin; c_[u] = e.rarg; rn_[u] = e.rnan;
         }
 #pragma unroll
         for (int u = 0; u < SEL_U; ++u) {
@@ -1566,14 +1567,15 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
                 else if (d < mv || (d == mv && (int)x < mc)) { mv = d; mc = (int)x; }
             }
             if (x != psa) {
-                if (rn != NO_COL) { const long long l = x * N + rn; if (l < mine.nan_idx) mine.nan_idx = l; }
-                if (c != NO_COL) {
-                    const long long l = x * N + c;
-                    if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
-                }
+                if (rn != NO_COL && nx < 0) { nx = (int)x; ncol = rn; }
+                if (c != NO_COL && (v < bv || (bx < 0 && v == bv))) { bv = v; bx = (int)x; bc = c; }
             }
         }
     }
+    ArgMin mine;
+    mine.v = bv;
+    mine.idx = bx >= 0 ? (long long)bx * N + bc : INF_IDX;
+    mine.nan_idx = nx >= 0 ? (long long)nx * N + ncol : INF_IDX;
 #pragma unroll
     for (int s = 1; s < WAVE; s <<= 1) {
         const double v2 = __shfl_xor(mv, s);
@@ -1700,6 +1702,8 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
             Q.sw[off + sa] = step_slot_word(k, new_slot, s_slot[sa]);
             Q.cnt[off + sa] = nA;                    // (read by later rounds only: sa is nobody's partner now)
             Q.death[off + sb] = k;
+            Q.sel2[off + sb].death = k;
+            Q.sel2[Q.n_total + off + sb].death = k;
             const int64_t o = off + n_merges;
             out_a[o] = s_cnt[0]; out_b[o] = s_cnt[1]; out_d[o] = mind;
         }
@@ -1768,9 +1772,9 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
             double rm;
             int ra, rn;
             if (r == psa) { rm = s_psa.mv; ra = s_psa.mc; rn = s_psa.nc; }
-            else { rm = rmin_r[r]; ra = rarg_r[r]; rn = rnan_r[r]; }
+            else { rm = sel_r[r].rmin; ra = sel_r[r].rarg; rn = sel_r[r].rnan; }
             Dm[sa * N + r] = d;
-            newrow_w[r] = d;
+            sel_w[r].newrow = d;
             if (variant == 1) {
                 Dm[r * N + sa] = d;
                 const bool nan_hit = (rn == sa || rn == sb);
@@ -1785,7 +1789,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
             } else if (ra == sb || rn == sb) {       // column sa keeps its stale value (A-9)
                 rescan = true;
             }
-            if (!rescan) { rmin_w[r] = rm; rarg_w[r] = ra; rnan_w[r] = rn; }
+            if (!rescan) { sel_w[r].rmin = rm; sel_w[r].rarg = ra; sel_w[r].rnan = rn; }
         }
         if (tid < 4 * STEP_WAVES) { s_rescan[tid] = rescan ? 1 : 0; s_dfin[tid] = d; }
         __syncthreads();
@@ -1795,7 +1799,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
             double mv2;
             int mc2, nc2;
             step_scan_row(Dm + r * N, N, death, k, sb, variant == 1 ? sa : -1, s_dfin[jj], lane, mv2, mc2, nc2);
-            if (lane == 0) { rmin_w[r] = mv2; rarg_w[r] = mc2; rnan_w[r] = nc2; }
+            if (lane == 0) { sel_w[r].rmin = mv2; sel_w[r].rarg = mc2; sel_w[r].rnan = nc2; }
         }
     }
     STEP_TICK(6);                                    // logs, distances, row caches, rescans

@@ -608,20 +608,17 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         StepArrays Q;
         void *pm = nullptr, *pe = nullptr, *pp = nullptr;
         const size_t nt = (size_t)n_total;
-        const size_t misc_bytes = nt * (2 + 2 + 1) * sizeof(double) + nt * sizeof(unsigned long long) +
-                                  (size_t)2 * n_prob * sizeof(StepState) + nt * 5 * sizeof(int32_t) + 64;
+        const size_t misc_bytes = nt * 2 * sizeof(StepSel) + nt * sizeof(double) + nt * sizeof(unsigned long long) +
+                                  (size_t)2 * n_prob * sizeof(StepState) + nt * sizeof(int32_t) + 64;
         if ((st = scratch(c, S_STEP_MISC, misc_bytes, &pm)) != SPKD_OK) return st;
         if ((st = scratch(c, S_STEP_EXM, nt * QREC * sizeof(double), &pe)) != SPKD_OK) return st;
         if ((st = scratch(c, S_STEP_PKM, nt * REC * sizeof(double), &pp)) != SPKD_OK) return st;
         Q.ex = B.ex; Q.pk = B.pk; Q.exm = (double*)pe; Q.pkm = (double*)pp;
-        Q.rmin2 = (double*)pm;
-        Q.newrow2 = Q.rmin2 + 2 * nt;
-        Q.cnt = Q.newrow2 + 2 * nt;
+        Q.sel2 = (StepSel*)pm;
+        Q.cnt = (double*)(Q.sel2 + 2 * nt);
         Q.sw = (unsigned long long*)(Q.cnt + nt);
         Q.state2 = (StepState*)(Q.sw + nt);
         Q.death = (int32_t*)(Q.state2 + 2 * n_prob);
-        Q.rarg2 = Q.death + nt;
-        Q.rnan2 = Q.rarg2 + 2 * nt;
         Q.n_total = n_total;
         Q.n_prob = (int32_t)n_prob;
         auto kstep = P->kind == SPKD_GLR ? k_ahc_step<true> : k_ahc_step<false>;
