@@ -397,6 +397,9 @@ __global__ __launch_bounds__(PT_WAVES * WAVE) void k_cluster_prep(
 
 __device__ __forceinline__ double finish_distance(int kind, double lambdac, double nA, double ldA,
                                                   double nC, double ldC, double ldx) {
+    // no contraction into FMAs here: the matrix kernel and the merge loops (four launch shapes)
+    // must round this expression alike whatever code surrounds the call
+#pragma clang fp contract(off)
     const double n = nA + nC;
     if (kind == SPKD_BIC) {
         double d = 0.5 * n * ldx - 0.5 * nA * ldA - 0.5 * nC * ldC;
@@ -1339,7 +1342,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_final(
 // Arithmetic, tie-breaks and NaN rules are those of k_ahc; results are bit-identical.
 // ---------------------------------------------------------------------------
 constexpr int STEP_WAVES = 4;
-constexpr int STEP_TPB = STEP_WAVES * WAVE;
+constexpr int STEP_WIDE_FROM = 1024;                       // problems larger than this: eight waves per workgroup
 constexpr int STEP_PARTNERS = 4 * STEP_WAVES - 1;          // + the merged cluster itself: 16 items, one wave pass each
 constexpr int ALIVE_ROUND = 0x7fffffff;
 constexpr int STEP_MAX_N = 16384;                          // (two int arrays of N in LDS)
@@ -1348,6 +1351,7 @@ struct StepState {
     int32_t done, n_merges;
     long long psa;           // the row the previous round rewrote (-1: none)
     double fmin;
+    double diag;             // D[psa][psa] (never rewritten; carried here so that no load depends on psa)
 };
 
 __host__ __device__ inline unsigned long long step_slot_word(int round, int new_slot, int old_slot) {
@@ -1392,7 +1396,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_step_init(
     const long long N = seg_off[p + 1] - off;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         StepState S;
-        S.done = 0; S.n_merges = 0; S.psa = -1; S.fmin = 0.0;
+        S.done = 0; S.n_merges = 0; S.psa = -1; S.fmin = 0.0; S.diag = 0.0;
         Q.state2[(size_t)1 * Q.n_prob + p] = S;
         Q.state2[(size_t)0 * Q.n_prob + p] = S;
     }
@@ -1451,13 +1455,18 @@ __device__ __forceinline__ void step_scan_row(const double* __restrict__ row, lo
 
 // round k (k = 1 .. n_max - 1): merge k of every problem that has not stopped.
 // grid (max(1, ceil((n_max - k - 1) / STEP_PARTNERS)), n_prob); dynamic LDS: 2 N_max ints.
-template <bool TWO>
-__global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
+// SW waves per workgroup: the first STEP_WAVES of them eliminate (one wave per SIMD, the pass needs
+// 156 VGPRs); with SW = 8 four more share the selection, the partner list and the rescans, which
+// are issue-bound per wave (15 clusters per thread at N = 3 860 with four waves) and idle at the
+// barriers through the pass.
+template <bool TWO, int SW>
+__global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
         int k, const int64_t* __restrict__ seg_off, int variant, int kind, int max_spk, double lambdac,
         double threshold, double* __restrict__ ld, double* __restrict__ aux,
         double* __restrict__ mat, const int64_t* __restrict__ mat_off, StepArrays Q,
         int32_t* __restrict__ out_a, int32_t* __restrict__ out_b, double* __restrict__ out_d,
         unsigned long long* stat_max, unsigned long long* stat_min, int* err) {
+    constexpr int TPB = SW * WAVE;
     extern __shared__ int32_t s_dyn[];               // [N] partner list | [N] current slot of a cluster (-1: dead)
     __shared__ double ldsA[QREC];
     __shared__ double s_auxA[AUX];
@@ -1465,10 +1474,8 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     __shared__ double s_dfin[4 * STEP_WAVES];
     __shared__ int s_rescan[4 * STEP_WAVES];
     struct RowRed { double mv, wmax, wmin; int mc, nc; };
-    __shared__ RowRed rred[STEP_WAVES];
-    __shared__ ArgMin red[STEP_WAVES];
-    __shared__ ArgMin best;
-    __shared__ RowRed s_psa;
+    __shared__ RowRed rred[SW];
+    __shared__ ArgMin red[SW];
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
@@ -1480,15 +1487,18 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
 #else
 #define STEP_TICK(i) ((void)0)
 #endif
+    // (the state, the problem's offsets: one batch of scalar loads, one trip to memory; nothing
+    // the selection loads next depends on the state)
     const StepState S = Q.state2[(size_t)(k & 1) * Q.n_prob + p];
     StepState* Snext = Q.state2 + (size_t)((k + 1) & 1) * Q.n_prob + p;
+    const int64_t off = seg_off[p];
+    const long long N = seg_off[p + 1] - off;
+    const int64_t moff = mat_off[p];
     const bool lead = blockIdx.x == 0;
     if (S.done) {                                    // a stopped problem: carry its state forward
         if (lead && tid == 0) *Snext = S;
         return;
     }
-    const int64_t off = seg_off[p];
-    const long long N = seg_off[p + 1] - off;
     const int n_merges = S.n_merges;
     const long long psa = S.psa;
     const long long m = N - n_merges;                // clusters alive now
@@ -1509,7 +1519,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     const int32_t* death = Q.death + off;
     const StepSel* sel_r = Q.sel2 + (size_t)rb * Q.n_total + off;
     StepSel* sel_w = Q.sel2 + (size_t)wb * Q.n_total + off;
-    double* Dm = mat + mat_off[p];
+    double* Dm = mat + moff;
     double* ldp = ld + off;
     const long long INF_IDX = 0x7fffffffffffffffLL;
     auto rec_quad = [&](int slot) -> const double* {
@@ -1521,7 +1531,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     // ---- S. the selection, by every workgroup: ONE pass over x = 0 .. N - 1 -- x as a column
     // of the row psa (its fresh cache; variant 1: the running statistics over the distances
     // round k - 1 evaluated) and x as a row of the arg-min over the row caches
-    const double diag_psa = psa >= 0 ? Dm[psa * N + psa] : 0.0;
+    const double diag_psa = S.diag;
     double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
     int mc = NO_COL, nc = NO_COL;
     // (a thread meets its clusters in ascending order, so "the smaller linear index on a tie" is
@@ -1532,13 +1542,13 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     // (eight clusters per thread at a time, all their loads in flight before the first is looked
     // at: a wave's lanes hold 64 consecutive clusters, chunk x / 64)
     constexpr int SEL_U = 8;
-    for (long long x0 = tid; x0 < N; x0 += (long long)SEL_U * STEP_TPB) {
+    for (long long x0 = tid; x0 < N; x0 += (long long)SEL_U * TPB) {
         int dth[SEL_U], c_[SEL_U], rn_[SEL_U];
         unsigned long long w_[SEL_U];
         double dn_[SEL_U], v_[SEL_U];
 #pragma unroll
         for (int u = 0; u < SEL_U; ++u) {
-            const long long x = x0 + (long long)u * STEP_TPB;
+            const long long x = x0 + (long long)u * TPB;
             const long long xc = x < N ? x : N - 1;
             const StepSel e = sel_r[xc];                  // (two 16-byte loads)
             w_[u] = Q.sw[off + xc];
@@ -1546,7 +1556,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         }
 #pragma unroll
         for (int u = 0; u < SEL_U; ++u) {
-            const long long x = x0 + (long long)u * STEP_TPB;
+            const long long x = x0 + (long long)u * TPB;
             const bool in = x < N;                     // (uniform per wave: a wave covers one chunk)
             const bool a = in && dth[u] >= k;
             const unsigned long long mk = __ballot(a);
@@ -1594,32 +1604,31 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         red[wave] = mine;
     }
     __syncthreads();
-    if (tid == 0) {
-        ArgMin b = red[0];
-        for (int w = 1; w < STEP_WAVES; ++w) argmin_merge(b, red[w]);
-        RowRed f = rred[0];
-        if (psa >= 0) {
-            for (int w = 1; w < STEP_WAVES; ++w) {
-                const RowRed o = rred[w];
-                if (o.mv < f.mv || (o.mv == f.mv && o.mc < f.mc)) { f.mv = o.mv; f.mc = o.mc; }
-                f.nc = o.nc < f.nc ? o.nc : f.nc;
-                if (o.wmax == o.wmax && (f.wmax != f.wmax || o.wmax > f.wmax)) f.wmax = o.wmax;
-                if (o.wmin == o.wmin && (f.wmin != f.wmin || o.wmin < f.wmin)) f.wmin = o.wmin;
-            }
-            if (lead && variant == 1) {
-                if (f.wmax == f.wmax) atomicMax(stat_max + p, dkey(f.wmax));
-                if (f.wmin == f.wmin) atomicMin(stat_min + p, dkey(f.wmin));
-            }
-            ArgMin own;                              // row psa as a candidate of the arg-min
-            own.v = f.mc != NO_COL ? f.mv : __builtin_huge_val();
-            own.idx = f.mc != NO_COL ? psa * N + f.mc : INF_IDX;
-            own.nan_idx = f.nc != NO_COL ? psa * N + f.nc : INF_IDX;
-            argmin_merge(b, own);
+    // every thread folds the waves' results for itself (SW entries each, broadcast reads): no
+    // second barrier, no trip of the winner through LDS
+    ArgMin best = red[0];
+#pragma unroll
+    for (int w = 1; w < SW; ++w) argmin_merge(best, red[w]);
+    RowRed s_psa = rred[0];
+    if (psa >= 0) {
+#pragma unroll
+        for (int w = 1; w < SW; ++w) {
+            const RowRed o = rred[w];
+            if (o.mv < s_psa.mv || (o.mv == s_psa.mv && o.mc < s_psa.mc)) { s_psa.mv = o.mv; s_psa.mc = o.mc; }
+            s_psa.nc = o.nc < s_psa.nc ? o.nc : s_psa.nc;
+            if (o.wmax == o.wmax && (s_psa.wmax != s_psa.wmax || o.wmax > s_psa.wmax)) s_psa.wmax = o.wmax;
+            if (o.wmin == o.wmin && (s_psa.wmin != s_psa.wmin || o.wmin < s_psa.wmin)) s_psa.wmin = o.wmin;
         }
-        s_psa = f;
-        best = b;
+        if (lead && tid == 0 && variant == 1) {
+            if (s_psa.wmax == s_psa.wmax) atomicMax(stat_max + p, dkey(s_psa.wmax));
+            if (s_psa.wmin == s_psa.wmin) atomicMin(stat_min + p, dkey(s_psa.wmin));
+        }
+        ArgMin own;                                  // row psa as a candidate of the arg-min
+        own.v = s_psa.mc != NO_COL ? s_psa.mv : __builtin_huge_val();
+        own.idx = s_psa.mc != NO_COL ? psa * N + s_psa.mc : INF_IDX;
+        own.nan_idx = s_psa.nc != NO_COL ? psa * N + s_psa.nc : INF_IDX;
+        argmin_merge(best, own);
     }
-    __syncthreads();
     STEP_TICK(2);                                    // selection: one pass + reductions
     const bool has_nan = best.nan_idx != INF_IDX;
     const double mind = has_nan ? __builtin_nan("") : best.v;
@@ -1630,22 +1639,24 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         if (lead && tid == 0) {
             if (go) atomicOr(err, ERR_DEGENERATE_MERGE);
             StepState T;
-            T.done = 1; T.n_merges = n_merges; T.psa = psa; T.fmin = mind;
+            T.done = 1; T.n_merges = n_merges; T.psa = psa; T.fmin = mind; T.diag = S.diag;
             *Snext = T;
         }
         return;
     }
     const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
+    double diag_sa = 0.0;
+    if (lead && tid == 0) diag_sa = Dm[sa * N + sa];   // for the next round's state
     // ---- M (first half). the two old records of the merged pair on their way to registers
     // while the partner list is being built
-    constexpr int M_PER = (QREC + STEP_TPB - 1) / STEP_TPB;
+    constexpr int M_PER = (QREC + TPB - 1) / TPB;
     double m_a[M_PER], m_b[M_PER];
     {
         const double* A0 = rec_quad(s_slot[sa]);
         const double* B0 = rec_quad(s_slot[sb]);
 #pragma unroll
         for (int u = 0; u < M_PER; ++u) {
-            const int e = tid + u * STEP_TPB;
+            const int e = tid + u * TPB;
             m_a[u] = A0[e < QREC ? e : 0];
             m_b[u] = B0[e < QREC ? e : 0];
         }
@@ -1673,7 +1684,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     __syncthreads();
     const int ca = s_base[sa >> 6] + __popcll(s_mask[sa >> 6] & ((1ull << (sa & 63)) - 1ull));
     const int cb = s_base[sb >> 6] + __popcll(s_mask[sb >> 6] & ((1ull << (sb & 63)) - 1ull));
-    for (long long x = tid; x < N; x += STEP_TPB) {
+    for (long long x = tid; x < N; x += TPB) {
         if (s_slot[x] < 0 || x == sa || x == sb) continue;
         const int ar = s_base[x >> 6] + __popcll(s_mask[x >> 6] & ((1ull << (x & 63)) - 1ull));
         s_ids[ar - (ar > ca ? 1 : 0) - (ar > cb ? 1 : 0)] = (int32_t)x;
@@ -1682,7 +1693,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     // ---- M (second half). the merged record, formed by every workgroup from the two old ones
 #pragma unroll
     for (int u = 0; u < M_PER; ++u) {
-        const int e = tid + u * STEP_TPB;
+        const int e = tid + u * TPB;
         if (e < QREC) ldsA[e] = m_a[u] + m_b[u];
     }
     __syncthreads();
@@ -1693,11 +1704,11 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         // the books: the merged record in its fresh slot (both layouts), the slot word, the
         // count, the death mark, the merge log
         double* Am = Q.exm + (off + n_merges) * QREC;
-        for (int e = tid; e < QREC; e += STEP_TPB) Am[e] = ldsA[e];
+        for (int e = tid; e < QREC; e += TPB) Am[e] = ldsA[e];
         const double* Ap = rec_packed(s_slot[sa]);
         const double* Bp = rec_packed(s_slot[sb]);
         double* Pm = Q.pkm + (off + n_merges) * REC;
-        for (int e = tid; e < REC; e += STEP_TPB) Pm[e] = Ap[e] + Bp[e];
+        for (int e = tid; e < REC; e += TPB) Pm[e] = Ap[e] + Bp[e];
         if (tid == 0) {
             Q.sw[off + sa] = step_slot_word(k, new_slot, s_slot[sa]);
             Q.cnt[off + sa] = nA;                    // (read by later rounds only: sa is nobody's partner now)
@@ -1725,6 +1736,17 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
     // s_ids[first + j - 1]
     const int first = (int)blockIdx.x * STEP_PARTNERS;
     const int mine_n = n_part - first < STEP_PARTNERS ? n_part - first : STEP_PARTNERS;   // partners here (>= 0)
+    // what the finish needs of a partner (its count, its log term, its row cache), asked for now:
+    // the answers arrive under the pass
+    const bool fin = tid >= 1 && tid <= mine_n;
+    const long long fin_r = fin ? (long long)s_ids[first + tid - 1] : 0;
+    double fin_nC = 0.0, fin_ld = 0.0;
+    StepSel fin_sel;
+    fin_sel.rmin = 0.0; fin_sel.newrow = 0.0; fin_sel.rarg = 0; fin_sel.rnan = 0; fin_sel.death = 0; fin_sel.pad = 0;
+    if (fin) {
+        fin_sel = sel_r[fin_r];
+        if (kind != SPKD_KL2) { fin_nC = Q.cnt[off + fin_r]; fin_ld = ldp[fin_r]; }
+    }
     if (kind != SPKD_KL2) {
         const int base = 4 * wave;
         if (base <= mine_n) {
@@ -1753,8 +1775,8 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         const int j = tid;
         bool rescan = false;
         double d = 0.0;
-        if (j >= 1 && j <= mine_n) {
-            const long long r = s_ids[first + j - 1];
+        if (fin) {
+            const long long r = fin_r;
             if (kind == SPKD_KL2) {
                 const double* a2 = aux + (off + r) * AUX;
                 double t1 = 0.0, t2 = 0.0;
@@ -1766,13 +1788,12 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
                 }
                 d = 0.5 * t1 + 0.5 * t2;
             } else {
-                const double nC = Q.cnt[off + r];
-                d = finish_distance(kind, lambdac, nA, ldA, nC, ldp[r], s_ldx[j]);
+                d = finish_distance(kind, lambdac, nA, ldA, fin_nC, fin_ld, s_ldx[j]);
             }
             double rm;
             int ra, rn;
             if (r == psa) { rm = s_psa.mv; ra = s_psa.mc; rn = s_psa.nc; }
-            else { rm = sel_r[r].rmin; ra = sel_r[r].rarg; rn = sel_r[r].rnan; }
+            else { rm = fin_sel.rmin; ra = fin_sel.rarg; rn = fin_sel.rnan; }
             Dm[sa * N + r] = d;
             sel_w[r].newrow = d;
             if (variant == 1) {
@@ -1793,7 +1814,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
         }
         if (tid < 4 * STEP_WAVES) { s_rescan[tid] = rescan ? 1 : 0; s_dfin[tid] = d; }
         __syncthreads();
-        for (int jj = 1 + wave; jj <= mine_n; jj += STEP_WAVES) {
+        for (int jj = 1 + wave; jj <= mine_n; jj += SW) {
             if (!s_rescan[jj]) continue;             // (wave-uniform)
             const long long r = s_ids[first + jj - 1];
             double mv2;
@@ -1808,7 +1829,7 @@ __global__ __launch_bounds__(STEP_TPB) void k_ahc_step(
 #endif
     if (lead && tid == 0) {
         StepState T;
-        T.done = 0; T.n_merges = n_merges + 1; T.psa = sa; T.fmin = mind;
+        T.done = 0; T.n_merges = n_merges + 1; T.psa = sa; T.fmin = mind; T.diag = diag_sa;
         *Snext = T;
     }
 }
