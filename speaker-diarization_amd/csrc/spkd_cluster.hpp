@@ -518,6 +518,7 @@ __device__ __forceinline__ void argmin_merge(ArgMin& x, const ArgMin& y) {
 // two merged clusters, so an iteration costs O(N) plus a few row rescans instead
 // of an O(N^2) scan, with numpy's first-occurrence / NaN semantics intact.
 #ifdef SPKD_PROFILE
+__device__ unsigned long long g_step_prof[8];     // profiling builds: clocks inside the selection of k_ahc_step
 __device__ unsigned long long g_ahc_prof[8];      // profiling builds: rows rescanned, merges, 5 phase clocks of k_ahc
 #endif
 constexpr int NO_COL = 0x7fffffff;
@@ -1345,7 +1346,49 @@ constexpr int STEP_WAVES = 4;
 constexpr int STEP_WIDE_FROM = 1024;                       // problems larger than this: eight waves per workgroup
 constexpr int STEP_PARTNERS = 4 * STEP_WAVES - 1;          // + the merged cluster itself: 16 items, one wave pass each
 constexpr int ALIVE_ROUND = 0x7fffffff;
-constexpr int STEP_MAX_N = 16384;                          // (two int arrays of N in LDS)
+constexpr int STEP_MAX_N = 16384;                          // (two int arrays of N in LDS; positions packed as row << 14 | column)
+constexpr int STEP_IDX_SHIFT = 14;
+
+// Wave-wide integer reductions without LDS: four DPP steps inside each row of 16 lanes (min and
+// max are idempotent: quad_perm xor 1, xor 2, row_half_mirror, row_mirror leave the row's result
+// in every lane), then the four rows by v_readlane and scalar arithmetic.  The result is uniform.
+// (The selection of k_ahc_step used 64-bit __shfl_xor butterflies with fp64 compares: six
+// dependent steps of ~14 ds_bpermute each, 3.8 k cycles per wave; these take ~150.)
+template <bool MAXOP>
+__device__ __forceinline__ unsigned wave_red_u32(unsigned x) {
+    auto op = [](unsigned a, unsigned b) { return MAXOP ? (a > b ? a : b) : (a < b ? a : b); };
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));   // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0), b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32), d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+    return op(op(a, b), op(c, d));
+}
+// inclusive prefix sum over the wave: four shifts inside a row of 16 (zeros shifted in), then
+// lane 15 of rows 0 and 2 into rows 1 and 3, lane 31 into rows 2 and 3
+__device__ __forceinline__ int wave_scan_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return x;
+}
+template <bool MAXOP>
+__device__ __forceinline__ unsigned long long wave_red_u64(unsigned long long k) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned h = wave_red_u32<MAXOP>(hi);
+    const unsigned l = wave_red_u32<MAXOP>(hi == h ? lo : (MAXOP ? 0u : 0xffffffffu));
+    return ((unsigned long long)h << 32) | l;
+}
+// the smallest (key, idx) pair of the wave, lexicographically
+__device__ __forceinline__ void wave_argmin_key(unsigned long long key, unsigned idx,
+                                                unsigned long long& okey, unsigned& oidx) {
+    okey = wave_red_u64<false>(key);
+    oidx = wave_red_u32<false>(key == okey ? idx : 0xffffffffu);
+}
 
 struct StepState {
     int32_t done, n_merges;
@@ -1473,9 +1516,9 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
     __shared__ double s_ldx[4 * STEP_WAVES];
     __shared__ double s_dfin[4 * STEP_WAVES];
     __shared__ int s_rescan[4 * STEP_WAVES];
-    struct RowRed { double mv, wmax, wmin; int mc, nc; };
-    __shared__ RowRed rred[SW];
-    __shared__ ArgMin red[SW];
+    struct RowRed { double mv; int mc, nc; };
+    struct WaveRed { unsigned long long kb, kr, kmax, kmin; unsigned ib, inan; int mc, nc; };
+    __shared__ WaveRed wred[SW];
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
@@ -1484,8 +1527,11 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
     // profiling builds: phase clocks of thread 0 of workgroup 0 (tools/step_phase_profile.py)
     unsigned long long st_t = clock64();
 #define STEP_TICK(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_ahc_prof[i], now_ - st_t); st_t = now_; } while (0)
+    unsigned long long st_f = st_t;
+#define STEP_FINE(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_step_prof[i], now_ - st_f); st_f = now_; } while (0)
 #else
 #define STEP_TICK(i) ((void)0)
+#define STEP_FINE(i) ((void)0)
 #endif
     // (the state, the problem's offsets: one batch of scalar loads, one trip to memory; nothing
     // the selection loads next depends on the state)
@@ -1499,6 +1545,7 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
         if (lead && tid == 0) *Snext = S;
         return;
     }
+    STEP_FINE(0);                                    // the state and the offsets are here
     const int n_merges = S.n_merges;
     const long long psa = S.psa;
     const long long m = N - n_merges;                // clusters alive now
@@ -1531,111 +1578,136 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
     // ---- S. the selection, by every workgroup: ONE pass over x = 0 .. N - 1 -- x as a column
     // of the row psa (its fresh cache; variant 1: the running statistics over the distances
     // round k - 1 evaluated) and x as a row of the arg-min over the row caches
+    // Everything is compared as integers: a distance by its order-preserving 64-bit key (dkey),
+    // a matrix position (row, column) by row << 14 | column (N <= 16 384: the order of the linear index).  A thread meets its clusters in
+    // ascending order, so on equal keys the one met first has the smaller index: a strict "<"
+    // against a running best that starts at the all-ones key (above every number's key) is the
+    // reference's (value, then index) order.  No branches per cluster, only selects.
     const double diag_psa = S.diag;
-    double mv = __builtin_huge_val(), wmax = __builtin_nan(""), wmin = __builtin_nan("");
+    const bool hp = psa >= 0, v1 = variant == 1;             // (uniform)
+    const unsigned NONE = 0xffffffffu;
+    unsigned long long kb = ~0ull, kr = ~0ull, kmax = 0ull, kmin = ~0ull;
+    unsigned ib = NONE, inan = NONE;
     int mc = NO_COL, nc = NO_COL;
-    // (a thread meets its clusters in ascending order, so "the smaller linear index on a tie" is
-    // "the one met first": the running best is kept as (value, row, column) in ints, the NaN
-    // index as the first row that has one -- no 64-bit index arithmetic per cluster)
-    double bv = __builtin_huge_val();
-    int bx = -1, bc = 0, nx = -1, ncol = 0;
     // (eight clusters per thread at a time, all their loads in flight before the first is looked
     // at: a wave's lanes hold 64 consecutive clusters, chunk x / 64)
     constexpr int SEL_U = 8;
-    for (long long x0 = tid; x0 < N; x0 += (long long)SEL_U * TPB) {
+    for (long long xb = 0; xb < N; xb += (long long)SEL_U * TPB) {       // (xb: uniform)
+        const long long x0 = xb + tid;
         int dth[SEL_U], c_[SEL_U], rn_[SEL_U];
         unsigned long long w_[SEL_U];
         double dn_[SEL_U], v_[SEL_U];
 #pragma unroll
         for (int u = 0; u < SEL_U; ++u) {
-            const long long x = x0 + (long long)u * TPB;
-            const long long xc = x < N ? x : N - 1;
-            const StepSel e = sel_r[xc];                  // (two 16-byte loads)
-            w_[u] = Q.sw[off + xc];
-            dth[u] = e.death; dn_[u] = e.newrow; v_[u] = e.rmin; c_[u] = e.rarg; rn_[u] = e.rnan;
+            if (xb + (long long)u * TPB < N) {         // (uniform: nobody has a cluster beyond)
+                const long long x = x0 + (long long)u * TPB;
+                const long long xc = x < N ? x : N - 1;
+                const StepSel e = sel_r[xc];              // (two 16-byte loads)
+                w_[u] = Q.sw[off + xc];
+                dth[u] = e.death; dn_[u] = e.newrow; v_[u] = e.rmin; c_[u] = e.rarg; rn_[u] = e.rnan;
+            }
         }
 #pragma unroll
         for (int u = 0; u < SEL_U; ++u) {
+            if (xb + (long long)u * TPB >= N) break;
             const long long x = x0 + (long long)u * TPB;
-            const bool in = x < N;                     // (uniform per wave: a wave covers one chunk)
+            const unsigned xu = (unsigned)x;
+            const bool in = x < N;                     // (a wave covers one chunk)
             const bool a = in && dth[u] >= k;
             const unsigned long long mk = __ballot(a);
             if (in) {
                 s_slot[x] = a ? step_slot_of(w_[u], k) : -1;
                 if (lane == 0) s_mask[x >> 6] = mk;
             }
-            if (!a) continue;
-            const double v = v_[u];
-            const int c = c_[u], rn = rn_[u];
-            if (psa >= 0) {
+            const bool np = a && x != psa;             // a row of the arg-min; a column of row psa other than psa
+            const unsigned long long kv = dkey(v_[u]);
+            const bool bet = np && c_[u] != NO_COL && kv < kb;
+            kb = bet ? kv : kb;
+            ib = bet ? ((xu << STEP_IDX_SHIFT) | (unsigned)c_[u]) : ib;
+            const unsigned ni = (np && rn_[u] != NO_COL) ? ((xu << STEP_IDX_SHIFT) | (unsigned)rn_[u]) : NONE;
+            inan = ni < inan ? ni : inan;
+            if (hp) {
                 const double d = x == psa ? diag_psa : dn_[u];
-                if (variant == 1 && x != psa && stat_valid(d)) {
-                    wmax = (wmax != wmax || d > wmax) ? d : wmax;
-                    wmin = (wmin != wmin || d < wmin) ? d : wmin;
+                const bool dnan = d != d;
+                const unsigned long long kd = dkey(d);
+                const bool bt = a && !dnan && kd < kr;
+                kr = bt ? kd : kr;
+                mc = bt ? (int)x : mc;
+                nc = (a && dnan && (int)x < nc) ? (int)x : nc;
+                if (v1) {
+                    const bool sv = np && stat_valid(d);
+                    kmax = (sv && kd > kmax) ? kd : kmax;
+                    kmin = (sv && kd < kmin) ? kd : kmin;
                 }
-                if (d != d) { if ((int)x < nc) nc = (int)x; }
-                else if (d < mv || (d == mv && (int)x < mc)) { mv = d; mc = (int)x; }
-            }
-            if (x != psa) {
-                if (rn != NO_COL && nx < 0) { nx = (int)x; ncol = rn; }
-                if (c != NO_COL && (v < bv || (bx < 0 && v == bv))) { bv = v; bx = (int)x; bc = c; }
             }
         }
     }
-    ArgMin mine;
-    mine.v = bv;
-    mine.idx = bx >= 0 ? (long long)bx * N + bc : INF_IDX;
-    mine.nan_idx = nx >= 0 ? (long long)nx * N + ncol : INF_IDX;
-#pragma unroll
-    for (int s = 1; s < WAVE; s <<= 1) {
-        const double v2 = __shfl_xor(mv, s);
-        const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
-        if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
-        nc = n2 < nc ? n2 : nc;
-        const double x = __shfl_xor(wmax, s), y = __shfl_xor(wmin, s);
-        if (x == x && (wmax != wmax || x > wmax)) wmax = x;
-        if (y == y && (wmin != wmin || y < wmin)) wmin = y;
-        ArgMin o;
-        o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
-        argmin_merge(mine, o);
-    }
-    if (lane == 0) {
-        rred[wave].mv = mv; rred[wave].mc = mc; rred[wave].nc = nc; rred[wave].wmax = wmax; rred[wave].wmin = wmin;
-        red[wave] = mine;
+    STEP_FINE(1);                                    // the pass over the clusters
+    {
+        WaveRed w;
+        wave_argmin_key(kb, ib, w.kb, w.ib);
+        w.inan = __any(inan != NONE) ? wave_red_u32<false>(inan) : NONE;
+        w.kr = ~0ull; w.mc = NO_COL; w.nc = NO_COL; w.kmax = 0ull; w.kmin = ~0ull;
+        if (hp) {
+            unsigned mcu;
+            wave_argmin_key(kr, (unsigned)mc, w.kr, mcu);
+            w.mc = (int)mcu;
+            if (__any(nc != NO_COL)) w.nc = (int)wave_red_u32<false>((unsigned)nc);
+            if (v1) { w.kmax = wave_red_u64<true>(kmax); w.kmin = wave_red_u64<false>(kmin); }
+        }
+        STEP_FINE(2);                                // the wave's reduction
+        if (lane == 0) wred[wave] = w;
     }
     __syncthreads();
-    // every thread folds the waves' results for itself (SW entries each, broadcast reads): no
-    // second barrier, no trip of the winner through LDS
-    ArgMin best = red[0];
+    // every thread folds the waves' results for itself (SW entries, broadcast reads): no second
+    // barrier, no trip of the winner through LDS
+    // (as a tree: the merges of one level do not depend on each other)
+    WaveRed fw[SW];
 #pragma unroll
-    for (int w = 1; w < SW; ++w) argmin_merge(best, red[w]);
-    RowRed s_psa = rred[0];
-    if (psa >= 0) {
+    for (int w = 0; w < SW; ++w) fw[w] = wred[w];
 #pragma unroll
-        for (int w = 1; w < SW; ++w) {
-            const RowRed o = rred[w];
-            if (o.mv < s_psa.mv || (o.mv == s_psa.mv && o.mc < s_psa.mc)) { s_psa.mv = o.mv; s_psa.mc = o.mc; }
-            s_psa.nc = o.nc < s_psa.nc ? o.nc : s_psa.nc;
-            if (o.wmax == o.wmax && (s_psa.wmax != s_psa.wmax || o.wmax > s_psa.wmax)) s_psa.wmax = o.wmax;
-            if (o.wmin == o.wmin && (s_psa.wmin != s_psa.wmin || o.wmin < s_psa.wmin)) s_psa.wmin = o.wmin;
+    for (int st = 1; st < SW; st <<= 1) {
+#pragma unroll
+        for (int w = 0; w + st < SW; w += 2 * st) {
+            WaveRed& x = fw[w];
+            const WaveRed& o = fw[w + st];
+            const bool b1 = o.kb < x.kb || (o.kb == x.kb && o.ib < x.ib);
+            x.kb = b1 ? o.kb : x.kb; x.ib = b1 ? o.ib : x.ib;
+            x.inan = o.inan < x.inan ? o.inan : x.inan;
+            const bool b2 = o.kr < x.kr || (o.kr == x.kr && o.mc < x.mc);
+            x.kr = b2 ? o.kr : x.kr; x.mc = b2 ? o.mc : x.mc;
+            x.nc = o.nc < x.nc ? o.nc : x.nc;
+            x.kmax = o.kmax > x.kmax ? o.kmax : x.kmax;
+            x.kmin = o.kmin < x.kmin ? o.kmin : x.kmin;
         }
-        if (lead && tid == 0 && variant == 1) {
-            if (s_psa.wmax == s_psa.wmax) atomicMax(stat_max + p, dkey(s_psa.wmax));
-            if (s_psa.wmin == s_psa.wmin) atomicMin(stat_min + p, dkey(s_psa.wmin));
-        }
-        ArgMin own;                                  // row psa as a candidate of the arg-min
-        own.v = s_psa.mc != NO_COL ? s_psa.mv : __builtin_huge_val();
-        own.idx = s_psa.mc != NO_COL ? psa * N + s_psa.mc : INF_IDX;
-        own.nan_idx = s_psa.nc != NO_COL ? psa * N + s_psa.nc : INF_IDX;
-        argmin_merge(best, own);
     }
+    WaveRed f = fw[0];
+    // row psa: its fresh cache (what the finish reads for r == psa), and its place in the arg-min
+    RowRed s_psa;
+    s_psa.mv = f.mc != NO_COL ? dkey_inv(f.kr) : __builtin_huge_val();
+    s_psa.mc = f.mc; s_psa.nc = f.nc;
+    if (hp) {
+        if (lead && tid == 0 && v1) {
+            if (f.kmax != 0ull) atomicMax(stat_max + p, f.kmax);
+            if (f.kmin != ~0ull) atomicMin(stat_min + p, f.kmin);
+        }
+        if (f.mc != NO_COL) {
+            const unsigned io = ((unsigned)psa << STEP_IDX_SHIFT) | (unsigned)f.mc;
+            if (f.kr < f.kb || (f.kr == f.kb && io < f.ib)) { f.kb = f.kr; f.ib = io; }
+        }
+        if (f.nc != NO_COL) {
+            const unsigned io = ((unsigned)psa << STEP_IDX_SHIFT) | (unsigned)f.nc;
+            f.inan = io < f.inan ? io : f.inan;
+        }
+    }
+    STEP_FINE(3);                                    // barrier + the fold over the waves
     STEP_TICK(2);                                    // selection: one pass + reductions
-    const bool has_nan = best.nan_idx != INF_IDX;
-    const double mind = has_nan ? __builtin_nan("") : best.v;
-    const long long index = has_nan ? best.nan_idx : best.idx;
+    const bool has_nan = f.inan != NONE;
+    const double mind = has_nan ? __builtin_nan("") : (f.ib != NONE ? dkey_inv(f.kb) : __builtin_huge_val());
+    const unsigned pos = has_nan ? f.inan : f.ib;    // (NONE: nothing to merge; `go` is false then unless max_spk forces)
     const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
-    const long long r0 = index / N, c0 = index - r0 * N;
-    if (!go || r0 == c0) {
+    const long long r0 = pos >> STEP_IDX_SHIFT, c0 = pos & ((1u << STEP_IDX_SHIFT) - 1u);
+    if (!go || r0 == c0 || pos == NONE) {            // (pos == NONE with go: no pair left to force)
         if (lead && tid == 0) {
             if (go) atomicOr(err, ERR_DEGENERATE_MERGE);
             StepState T;
@@ -1671,14 +1743,9 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
         for (int c1 = 0; c1 < nch; c1 += WAVE) {
             const int ch = c1 + lane;
             const int cnt = ch < nch ? __popcll(s_mask[ch]) : 0;
-            int inc = cnt;
-#pragma unroll
-            for (int sft = 1; sft < WAVE; sft <<= 1) {
-                const int up = __shfl_up(inc, sft);
-                if (lane >= sft) inc += up;
-            }
+            const int inc = wave_scan_i32(cnt);
             if (ch < nch) s_base[ch] = run + inc - cnt;
-            run += __shfl(inc, WAVE - 1);
+            run += __builtin_amdgcn_readlane(inc, WAVE - 1);
         }
     }
     __syncthreads();

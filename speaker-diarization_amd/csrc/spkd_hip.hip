@@ -1263,6 +1263,13 @@ extern "C" int spkd_debug_ahc_prof(unsigned long long* out4) {
     return 0;
 }
 
+extern "C" int spkd_debug_step_prof(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(spkd::g_step_prof), sizeof z) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(spkd::g_step_prof), z, sizeof z) != hipSuccess) return 1;
+    return 0;
+}
+
 extern "C" int spkd_debug_pass_prof(unsigned long long* out4) {
     unsigned long long z[4] = {0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(spkd::g_pass_prof), sizeof z) != hipSuccess) return 1;

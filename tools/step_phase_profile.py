@@ -28,8 +28,10 @@ def main():
     f = [pipeline.BatchFile(0, int(feats.shape[0]), vt)]
     ctx = hipabi.Context(0, torch.cuda.current_stream().cuda_stream)
     a8 = (C.c_ulonglong * 8)()
+    f8 = (C.c_ulonglong * 8)()
     for it in range(2):
         lib.spkd_debug_ahc_prof(a8)                    # (zeroes the counters)
+        lib.spkd_debug_step_prof(f8)
         tm = {}
         pipeline.diarize_batch(ctx, feats.data_ptr(), int(feats.shape[0]), f, timings=tm, fused=True)
         lib.spkd_debug_ahc_prof(a8)
@@ -40,6 +42,9 @@ def main():
         for name, x in zip(('selection pass + reductions', 'partner list + merged record', 'bookkeeping (workgroup 0)',
                             'the pass (loads + elimination)', 'logs, distances, caches, rescans'), v[2:7]):
             print('  %-34s %5.1f %%  %8.0f cycles/round' % (name, 100.0 * x / tot, x / n))
+        lib.spkd_debug_step_prof(f8)
+        print('  inside the selection: state + offsets %.0f, the pass over the clusters %.0f, wave reduction %.0f, '
+              'barrier + fold %.0f cycles/round' % tuple(x / n for x in list(f8)[:4]))
 
 
 if __name__ == '__main__':
