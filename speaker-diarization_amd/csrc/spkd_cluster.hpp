@@ -1533,13 +1533,17 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
 #define STEP_TICK(i) ((void)0)
 #define STEP_FINE(i) ((void)0)
 #endif
-    // (the state, the problem's offsets: one batch of scalar loads, one trip to memory; nothing
-    // the selection loads next depends on the state)
-    const StepState S = Q.state2[(size_t)(k & 1) * Q.n_prob + p];
+    // The prologue's scalar loads in two batches -- the kernel arguments, then what they point to
+    // (the state, the problem's offsets) -- pinned here: left to itself the compiler loads each
+    // argument in the block that first uses it, six dependent trips to memory one after the
+    // other before the selection's first vector load is issued.
+    asm volatile("" :: "s"(Q.state2), "s"(Q.sel2), "s"(Q.sw), "s"(Q.ex), "s"(Q.exm), "s"(Q.n_total), "s"(Q.n_prob),
+                 "s"(seg_off), "s"(mat_off), "s"(mat), "s"(k));
+    StepState S = Q.state2[(size_t)(k & 1) * Q.n_prob + p];
     StepState* Snext = Q.state2 + (size_t)((k + 1) & 1) * Q.n_prob + p;
-    const int64_t off = seg_off[p];
-    const long long N = seg_off[p + 1] - off;
-    const int64_t moff = mat_off[p];
+    int64_t off = seg_off[p], off_end = seg_off[p + 1], moff = mat_off[p];
+    asm volatile("" :: "s"(S.done), "s"(S.n_merges), "s"(off), "s"(off_end), "s"(moff));
+    const long long N = off_end - off;
     const bool lead = blockIdx.x == 0;
     if (S.done) {                                    // a stopped problem: carry its state forward
         if (lead && tid == 0) *Snext = S;
