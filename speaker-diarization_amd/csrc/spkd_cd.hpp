@@ -98,6 +98,9 @@ __device__ __forceinline__ void single_rows_from_tri(const double* rec, double (
 constexpr int ERR_SWEEP = 16;                                // internal: a wanted position behind the sweep
 
 template <int NW> struct GwShape;
+// (8: the sweep of 4 -- 210 threads accumulate, all 512 stage the tile -- with twice the waves
+// for the determinants: a file with fewer turns than the chip has CUs, two waves per SIMD)
+template <> struct GwShape<8> { static constexpr int BR = 2, BC = 2, TILE = 128; };
 template <> struct GwShape<4> { static constexpr int BR = 2, BC = 2, TILE = 128; };
 template <> struct GwShape<2> { static constexpr int BR = 4, BC = 2, TILE = 64; };
 template <> struct GwShape<1> { static constexpr int BR = 4, BC = 4, TILE = 32; };
@@ -666,7 +669,7 @@ struct GwState {
 };
 
 template <int NW>
-__global__ __launch_bounds__(Gw<NW>::TPB, 2) void k_gw(
+__global__ __launch_bounds__(Gw<NW>::TPB, NW == 8 ? 1 : 2) void k_gw(
         const float* __restrict__ frames, const TurnDesc* __restrict__ turns, spkd_cd_params P,
         double* __restrict__ cache_all, double* __restrict__ cand_all,
         int32_t* __restrict__ n_win, double* __restrict__ win_maxd, int32_t* __restrict__ win_det,

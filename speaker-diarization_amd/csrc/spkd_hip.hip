@@ -170,6 +170,7 @@ static spkd_status create_ctx(int device, void* stream, bool borrow, spkd_ctx** 
     int lds_max = 0;
     c->gw_lds_ok = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess &&
                    Gw<4>::LDS_BYTES <= lds_max &&
+                   hipFuncSetAttribute((const void*)k_gw<8>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<8>::LDS_BYTES) == hipSuccess &&
                    hipFuncSetAttribute((const void*)k_gw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<4>::LDS_BYTES) == hipSuccess &&
                    hipFuncSetAttribute((const void*)k_gw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<2>::LDS_BYTES) == hipSuccess &&
                    hipFuncSetAttribute((const void*)k_gw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Gw<1>::LDS_BYTES) == hipSuccess;
@@ -780,6 +781,7 @@ spkd_status build_turns(spkd_ctx* c, int64_t n_frames, const int64_t* hb, const 
 namespace {
 // from this many turns on, a wave per turn (2 048 wave slots on the chip at two waves per SIMD)
 constexpr int64_t GW_WAVE_PER_TURN_FROM = 4096;
+constexpr int64_t GW_EIGHT_WAVES_UP_TO = 256;           // a workgroup per CU: eight waves per turn
 spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const int64_t* hb,
                     const int64_t* he, int64_t n_turns, const spkd_cd_params* P, const int64_t* h_ev_off,
                     int check_capacity, int32_t* h_n_win, double* h_win_maxd, int32_t* h_win_det,
@@ -831,14 +833,16 @@ spkd_status gw_impl(spkd_ctx* c, const float* d_frames, int64_t n_frames, const 
     // phases of its turn, the SIMD's other wave belongs to another turn.  The variants give
     // bit-identical results (same sums, same eliminations, same decisions).
     int nw = c->gw_waves;
-    if (nw != 1 && nw != 2 && nw != 4) nw = n_turns >= GW_WAVE_PER_TURN_FROM ? 1 : 4;
+    if (nw != 1 && nw != 2 && nw != 4 && nw != 8)
+        nw = n_turns >= GW_WAVE_PER_TURN_FROM ? 1 : (n_turns <= GW_EIGHT_WAVES_UP_TO ? 8 : 4);
 #define SPKD_GW_LAUNCH(NW_)                                                                                     \
     hipLaunchKernelGGL(k_gw<NW_>, dim3((unsigned)n_turns), dim3(Gw<NW_>::TPB), Gw<NW_>::LDS_BYTES, c->stream, \
                        d_frames, (const TurnDesc*)d_turns, *P, (double*)d_snap, (double*)d_cand,               \
                        (int32_t*)d_i32a, (double*)d_d0, (int32_t*)d_i32b, (double*)d_d1, (double*)d_d2,        \
                        (double*)d_d3, (double*)d_d4, d_seg_stats, (spkd_cand_log*)d_log, (long long)log_cap,   \
                        c->d_counter, c->d_err)
-    TIMED(c, SPKD_T_GW, if (nw == 1) SPKD_GW_LAUNCH(1); else if (nw == 2) SPKD_GW_LAUNCH(2); else SPKD_GW_LAUNCH(4));
+    TIMED(c, SPKD_T_GW, if (nw == 1) SPKD_GW_LAUNCH(1); else if (nw == 2) SPKD_GW_LAUNCH(2);
+                        else if (nw == 8) SPKD_GW_LAUNCH(8); else SPKD_GW_LAUNCH(4));
 #undef SPKD_GW_LAUNCH
     HIPCHK(c, hipGetLastError());
     unsigned long long cnt2[2] = {0ull, 0ull};

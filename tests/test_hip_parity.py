@@ -392,3 +392,32 @@ def test_event_capacity_is_a_first_guess_that_doubles_until_it_fits(eng):
             assert np.array_equal(ref[k][o1:o1 + nd], small[k][o2:o2 + nd])
     # capacities the kernel would have refused at the first try
     assert int(small['off'][-1]) >= int(ref['n_win'].sum())
+
+
+@pytest.mark.parametrize('kind', ['BIC', 'GLR'])
+def test_gw_wave_shapes_agree(eng, kind, monkeypatch):
+    """k_gw runs a turn on one, two, four or eight waves (chosen by the number of turns;
+    SPKD_GW_WAVES pins it): the sums, the eliminations and the decisions are the same, so every
+    output array is bit-identical."""
+    import torch
+    hipabi = pkg('hipabi')
+    feats, vad, _ = session({'seed': 7001, 'seconds': 400, 'n_speakers': 4, 'kwargs': {},
+                             'frames': 50000, 'sha256': json.load(open(os.path.join(
+                                 ROOT, 'tests/golden/functions.json')))['session']['sha256']})
+    eng.set_features(feats)
+    b = np.array([s for (s, e) in vad], dtype=np.int64)
+    e = np.array([e_ for (s, e_) in vad], dtype=np.int64)
+    p = hipabi.CdParams(hipabi.KINDS[kind], 0, 1.0, 0.0, 125.0, 375.0, 12.0, 125.0)
+    got = {}
+    for nw in (1, 2, 4, 8):
+        monkeypatch.setenv('SPKD_GW_WAVES', str(nw))
+        ctx = hipabi.Context(0, torch.cuda.current_stream().cuda_stream)      # (reads the switch when it is made)
+        try:
+            got[nw] = ctx.gw(eng.d_frames, eng.n_frames, b, e, p)
+        finally:
+            ctx.close()
+    ref = got[4]
+    assert int(ref['win_det'].sum()) > 5
+    for nw in (1, 2, 8):
+        for k in ('n_win', 'off', 'final_start', 'win_det', 'win_maxd', 'det_start', 'det_maxi', 'det_d'):
+            assert np.array_equal(ref[k], got[nw][k], equal_nan=(ref[k].dtype.kind == 'f')), (nw, k)
