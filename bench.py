@@ -713,7 +713,8 @@ def other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, lo
         out[name] = {'ms': round(float(np.median(walls[1:])), 3), 'segments': int(len(rows[0])),
                      'speakers_found': int(rows[0][:, 2].max()) if len(rows[0]) else 0,
                      'xRT': round(secs / (float(np.median(walls[1:])) / 1e3), 0),
-                     'k_gw_ms': g('gw'), 'k_matrix_ms': g('matrix'), 'ahc_ms': g('ahc')}
+                     'k_gw_ms': g('gw'), 'k_matrix_ms': g('matrix'), 'ahc_ms': g('ahc'),
+                     'wall_ms': {k[5:]: round(float(np.mean(v)), 3) for k, v in tm.items() if k.startswith('wall_')}}
         if name == 'config2_1h_4spk':
             # the reference's DEFAULT stand-alone mode on the same file: -m sw -d GLR -w 5.0 -st 0.5
             # (spk-change-detection.py:436-447): distances of every sliding window of every VAD turn
