@@ -270,7 +270,7 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
     using G = Gw<NW>;
 #ifdef SPKD_PROFILE
     unsigned long long sw_acc[3] = {0ull, 0ull, 0ull};
-    unsigned long long sw_t = clock64();
+    unsigned long long sw_t = clock64(), sw_reached = 0ull;
 #define SW_TICK(i) do { const unsigned long long now_ = clock64(); sw_acc[i] += now_ - sw_t; sw_t = now_; } while (0)
 #else
 #define SW_TICK(i) ((void)0)
@@ -287,6 +287,9 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
             SW_TICK(0);
             want = on_reach(pos);
             SW_TICK(1);
+#ifdef SPKD_PROFILE
+            ++sw_reached;
+#endif
             if (want < 0) break;
             continue;
         }
@@ -361,6 +364,7 @@ __device__ __forceinline__ void gw_sweep(const SPKD_GLOBAL float* fr, float* xs,
 #ifdef SPKD_PROFILE
     SW_TICK(0);
     if (tid == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_gw_prof[8 + i], sw_acc[i]);
+    if (tid == 0) atomicAdd(&g_gw_prof[11], sw_reached);            // positions reached = records left
 #endif
 }
 

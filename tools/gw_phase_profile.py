@@ -48,6 +48,7 @@ def main():
         print('  items %d = %.1f per scan; wave passes %d = %.2f per scan' % (v[7], v[7] / max(v[4], 1), v[6], v[6] / max(v[4], 1)))
         for name, x in zip(('sweep: accumulate', 'sweep: dumps', 'sweep: staging'), v[8:11]):
             print('    %-18s %8.0f cycles/scan' % (name, x / max(v[4], 1)))
+        print('    records left by the sweep: %.2f per scan, %.0f cycles each' % (v[11] / max(v[4], 1), v[9] / max(v[11], 1)))
     # the merge loop: how many row caches a merge invalidates (each is a full row rescan)
     segs = pipeline.change_detect_batch(ctx, frames.data_ptr(), files_n * T, files, 125.0, pipeline.DIA2_CD)
     a4 = (C.c_ulonglong * 8)()
