@@ -33,6 +33,7 @@ import hashlib
 import importlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -497,6 +498,7 @@ def main():
         if world == 1 and not args.no_extras and depth == 1:
             res['value_incl_h2d'] = with_uploads(torch, dev, args, frames, total, files, pipeline, ctx, cl, fused, digest0)
             res['dropin_scripts_wall_s'] = dropin_wall(args, synth, first_host)
+            res['host_driven_modes_1h'] = host_driven_modes(args, synth, first_host, local)
         if world == 1 and not args.no_extras:
             res['hbm_copy_GBps'] = round(copy_rate(torch, dev), 1)
             res['other_configs'] = other_configs(torch, dev, hipabi, pipeline, synth_device, vad_times, ctx, local)
@@ -674,6 +676,58 @@ def dropin_wall(args, synth, first_host):
            'xRT': round(args.seconds / (t2 - t0), 1),
            'note': './spk-change-detection.py + ./spk-clustering.py as child processes on one file '
                    '(process start, imports, library load, context, .fea read and upload included)'}
+    return out
+
+
+def host_driven_modes(args, synth, first_host, local):
+    """The reference's host-driven modes on ONE 1 h file, in process, on an engine of their own:
+    `-m m` (merge_rec, spk-change-detection.py:136-177: one pair distance and one decision per
+    recipe line, each decision behind a synchronisation) over the growing-window output, with BIC
+    and GLR, and `-m in` (spk_cluster_in, spk-clustering.py:136-175: every segment against every
+    cluster so far).  Wall time of the library calls only (recipes in memory files, features
+    uploaded before the clock starts is NOT possible here: the drivers load the .fea themselves,
+    so the 70 MB read + upload is inside)."""
+    import importlib
+    import io
+    import tempfile
+    cli = importlib.import_module(PKG + '.cli')
+    engine = importlib.import_module(PKG + '.engine')
+    out = {}
+    eng = engine.HipEngine(local)
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            _write_session(tmp, synth, first_host[0], first_host[1])
+            fea = os.path.join(tmp, 'fea') + '/'
+            spkc = os.path.join(tmp, 'spkc.recipe')
+            cli.main_change_detection([os.path.join(tmp, 'vad.recipe'), fea, '-o', spkc] + CD_ARGS,
+                                      engine=eng, stdout=io.StringIO())
+            n_lines = open(spkc).read().count('\n')
+            for tag, extra in (('merge_bic', ['-m', 'm', '-d', 'BIC', '-l', '1.3']),
+                               ('merge_glr', ['-m', 'm', '-d', 'GLR', '-t', '1500'])):
+                walls = []
+                for it in range(3):
+                    t0 = time.perf_counter()
+                    cli.main_change_detection([spkc, fea, '-o', os.path.join(tmp, tag + '.recipe')] + extra,
+                                              engine=eng, stdout=io.StringIO())
+                    walls.append(time.perf_counter() - t0)
+                kept = open(os.path.join(tmp, tag + '.recipe')).read().count('\n')
+                out[tag] = {'ms': round(1e3 * float(np.median(walls)), 2), 'decisions': n_lines - 1, 'lines_out': kept,
+                            'us_per_decision': round(1e6 * float(np.median(walls)) / max(n_lines - 1, 1), 1)}
+            walls = []
+            for it in range(3):
+                t0 = time.perf_counter()
+                cli.main_clustering([spkc, fea, '-o', os.path.join(tmp, 'in.recipe'), '-m', 'in', '-l', '1.3'],
+                                    variant=1, engine=eng, stdout=io.StringIO())
+                walls.append(time.perf_counter() - t0)
+            spk = len(set(re.findall(r'speaker=(\S+)', open(os.path.join(tmp, 'in.recipe')).read())))
+            out['cluster_in_bic'] = {'ms': round(1e3 * float(np.median(walls)), 2), 'segments': n_lines, 'speakers': spk,
+                                     'us_per_segment': round(1e6 * float(np.median(walls)) / max(n_lines, 1), 1)}
+    except Exception as e:                               # a measurement beside the line, never the line itself
+        out['error'] = repr(e)[-300:]
+    finally:
+        eng.close()
+    out['note'] = ('in-process runs of the drop-in drivers on a 1 h file (.fea read + upload inside): every decision of '
+                   'these modes is a library call and a synchronisation, the serial chain is the reference\'s own')
     return out
 
 

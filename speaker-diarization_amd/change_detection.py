@@ -14,6 +14,10 @@ Split of labour
   * merge (``m``): one distance per recipe line, decision dependent -> host loop
     over ``engine.pair_terms``; reproduces the frozen ``c1`` of the 5-argument
     ``bic`` called without ``i``/``saved`` (CD:72,84-90,149).
+    A decision that does NOT merge leaves the next pair of lines as they stand in
+    the recipe, so the terms of every adjacent pair of a file are taken in ONE
+    batched call up front and only the decisions behind a merge (whose left side
+    is a range no recipe line names) go back to the device one by one.
 """
 import math
 import sys
@@ -65,6 +69,7 @@ class ChangeDetectionRun(object):
         self.total_segments = 0
         self._frozen_c1 = None          # A-8
         self._prev = None               # merge_rec.prev
+        self._ahead = {}                # merge mode: terms of the adjacent pairs of the current file
 
     # ----------------------------------------------------------------- counters
     def _window_stat(self, d):
@@ -208,16 +213,43 @@ class ChangeDetectionRun(object):
         writer.write(rl, end, (lna_end - lna_start) * o.rate, lna_start, 'spk_turn')
 
     # ----------------------------------------------------------------- merge
-    def _merge_distance(self, nframes, prev, nxt):
-        o = self.o
-        rate = o.rate
+    def _merge_ranges(self, nframes, prev, nxt):
+        rate = self.o.rate
         clamp = lambda t: max(0, min(int(t), nframes))
         a = (clamp(prev[2] * rate), clamp(prev[3] * rate))
         b = (clamp(nxt[2] * rate), clamp(nxt[3] * rate))
-        a = (a[0], max(a))
-        b = (b[0], max(b))
-        t = self.eng.pair_terms([([a], [b])], want_glr=(o.distance == 'GLR'),
-                                want_kl2=(o.distance == 'KL2'))[0]
+        return (a[0], max(a)), (b[0], max(b))
+
+    def _merge_speculate(self, recipe, l, nframes):
+        """Terms of every adjacent pair of lines of the file that starts at recipe[l], as the
+        recipe names them, in one engine call -> {(a, b): terms}.  A pair with a non-finite
+        covariance makes the reference raise AT that pair, after the lines before it were
+        written: then nothing is taken ahead and every decision makes its own call."""
+        o = self.o
+        jobs, keys, seen = [], [], set()
+        wav = recipe[l][0]
+        while l + 1 < len(recipe) and recipe[l + 1][0] == wav:
+            a, b = self._merge_ranges(nframes, recipe[l], recipe[l + 1])
+            if (a, b) not in seen:
+                seen.add((a, b))
+                keys.append((a, b))
+                jobs.append(([a], [b]))
+            l += 1
+        if len(jobs) < 2:
+            return {}
+        try:
+            terms = self.eng.pair_terms(jobs, want_glr=(o.distance == 'GLR'), want_kl2=(o.distance == 'KL2'))
+        except ValueError:
+            return {}
+        return dict(zip(keys, terms))
+
+    def _merge_distance(self, nframes, prev, nxt):
+        o = self.o
+        a, b = self._merge_ranges(nframes, prev, nxt)
+        t = self._ahead.get((a, b))
+        if t is None:
+            t = self.eng.pair_terms([([a], [b])], want_glr=(o.distance == 'GLR'),
+                                    want_kl2=(o.distance == 'KL2'))[0]
         if o.distance == 'BIC':
             if self._frozen_c1 is None:
                 self._frozen_c1 = 0.5 * t.n1 * t.logdet1
@@ -255,6 +287,7 @@ class ChangeDetectionRun(object):
             if recipe[l][0] != this_wav:
                 this_wav = recipe[l][0]
                 nframes = self._load(recipe[l])
+                self._ahead = self._merge_speculate(recipe, l, nframes)
             if l + 1 < len(recipe):
                 if recipe[l + 1][0] != this_wav:
                     l += 1

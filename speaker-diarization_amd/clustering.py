@@ -54,6 +54,7 @@ class ClusteringRun(object):
             feaio.fea_path(recline[0], self.feapath, self.feaext, join=(self.o.variant == 2)))
         self.eng.set_features(feats)
         self.nframes = feats.shape[0]
+        self._spk_sets = None           # (the clamped frame ranges depend on the file's length)
 
     def _frames(self, a, b):
         """int() truncation + the clamping a numpy slice applies (CL1:46-52)."""
@@ -106,14 +107,19 @@ class ClusteringRun(object):
         else:
             start = rl[2] * o.rate
             end = rl[3] * o.rate
-        seg = [self._frames(start, end)]
-        jobs = [([self._frames(s[0], s[1]) for s in spk], seg) for spk in self.speakers]
-        terms = self.eng.pair_terms(jobs, want_glr=(o.distance == 'GLR'),
-                                    want_kl2=(o.distance == 'KL2'))
+        # every cluster's frame ranges as one tuple, kept across calls and extended when a segment
+        # joins: rebuilding them from the float times for every new segment is quadratic in the
+        # number of segments, and the engine keys its record cache on exactly these tuples
+        seg_r = self._frames(start, end)
+        seg = (seg_r,)
+        if self._spk_sets is None or len(self._spk_sets) != len(self.speakers):
+            self._spk_sets = [tuple(self._frames(s[0], s[1]) for s in spk) for spk in self.speakers]
+        jobs = [(spk_set, seg) for spk_set in self._spk_sets]
+        dists = [self._distance(t) for t in self.eng.pair_terms(jobs, want_glr=(o.distance == 'GLR'),
+                                                                want_kl2=(o.distance == 'KL2'))]
         mind = MAXINT
         best = None
-        for k, t in enumerate(terms):
-            d = self._distance(t)
+        for k, d in enumerate(dists):
             if o.tt:
                 self.say('Time:', end, '- Distance:', d, '- Speaker:', k + 1)
             if not _isinf(d):
@@ -126,9 +132,11 @@ class ClusteringRun(object):
                     best = k
         if mind <= o.threshold:
             self.speakers[best].append((start, end))
+            self._spk_sets[best] = self._spk_sets[best] + seg
             writer.write(rl, start, end, 0, 'speaker_' + str(best + 1))
         else:
             self.speakers.append([(start, end)])
+            self._spk_sets.append(seg)
             writer.write(rl, start, end, 0, 'speaker_' + str(len(self.speakers)))
 
     # ----------------------------------------------------------------- hierarchical

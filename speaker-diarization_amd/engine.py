@@ -22,9 +22,23 @@ class HipEngine(object):
         self._owned = []
         self.last_ms = {}
         self.ahc_path = hipabi.AHC_AUTO     # AHC_MONO / AHC_WIDE force one launch shape
+        # pair_terms: statistics records of the frame sets seen so far on this file, on the
+        # device, keyed by the set itself.  The host-driven modes ask for the same sets again
+        # and again (spk_cluster_in: every cluster against every new segment, one cluster changed
+        # since the last call; merge_rec: the next line of the recipe); a record depends on its
+        # set alone, so a cached one is the recomputed one bit for bit.
+        self._rec_cap = 4096
+        self._rec_buf = None
+        self._rec_slot = {}
 
     # ------------------------------------------------------------- memory
+    def _forget_records(self):
+        self._rec_slot = {}
+
     def close(self):
+        if self._rec_buf is not None:
+            self.ctx.dev_free(self._rec_buf)
+            self._rec_buf = None
         for p in self._owned:
             self.ctx.dev_free(p)
         self._owned = []
@@ -45,6 +59,7 @@ class HipEngine(object):
         if feats.nbytes:
             self.ctx.h2d(self.d_frames, feats)
         self.n_frames = feats.shape[0]
+        self._forget_records()
 
     def set_device_features(self, d_ptr, n_frames):
         """Use frames already resident in HBM (e.g. ``tensor.data_ptr()``)."""
@@ -53,6 +68,7 @@ class HipEngine(object):
             self._owned.remove(self.d_frames)
         self.d_frames = d_ptr
         self.n_frames = n_frames
+        self._forget_records()
 
     @staticmethod
     def _raise_nonfinite(st):
@@ -87,17 +103,44 @@ class HipEngine(object):
         return out
 
     # ------------------------------------------------------------- pair terms
+    def _record_slots(self, sets):
+        """Slots (in the engine's record buffer) of the statistics records of `sets`; the missing
+        ones are computed, in one launch, into the next free slots."""
+        keys = [r if type(r) is tuple else tuple(tuple(x) for x in r) for r in sets]      # (a tuple: of tuples)
+        missing = []
+        for k in keys:
+            if k not in self._rec_slot and k not in missing:
+                missing.append(k)
+        if self._rec_buf is None or len(self._rec_slot) + len(missing) > self._rec_cap:
+            # full (or first use): start over with room for this call
+            self._rec_cap = max(self._rec_cap, 2 * len(keys))
+            if self._rec_buf is not None:
+                self.ctx.dev_free(self._rec_buf)
+            self._rec_buf = self.ctx.dev_alloc(self._rec_cap * hipabi.REC * 8)
+            self._rec_slot = {}
+            missing = []
+            for k in keys:
+                if k not in missing:
+                    missing.append(k)
+        if missing:
+            b, e, s_ = [], [], []
+            for i, ranges in enumerate(missing):
+                for (x, y) in ranges:
+                    b.append(x); e.append(y); s_.append(i)
+            first = len(self._rec_slot)
+            self.ctx.set_stats(self.d_frames, self.n_frames, b, e, s_, len(missing),
+                               self._rec_buf + first * hipabi.REC * 8)
+            for i, k in enumerate(missing):
+                self._rec_slot[k] = first + i
+        return [self._rec_slot[k] for k in keys]
+
     def pair_terms(self, jobs, want_glr=False, want_kl2=False):
-        sets, ia, ib = [], [], []
+        sets = []
         for ra, rb in jobs:
-            ia.append(len(sets)); sets.append(list(ra))
-            ib.append(len(sets)); sets.append(list(rb))
-        d = self._stats_of_sets(sets)
-        try:
-            flags = (hipabi.WANT_GLR if want_glr else 0) | (hipabi.WANT_KL2 if want_kl2 else 0)
-            out, st = self.ctx.pair_terms(d, ia, ib, flags)
-        finally:
-            self.ctx.dev_free(d)
+            sets.append(ra); sets.append(rb)
+        slots = self._record_slots(sets)
+        flags = (hipabi.WANT_GLR if want_glr else 0) | (hipabi.WANT_KL2 if want_kl2 else 0)
+        out, st = self.ctx.pair_terms(self._rec_buf, slots[0::2], slots[1::2], flags)
         self._raise_nonfinite(st)
         res = []
         for row in out:

@@ -274,3 +274,53 @@ def test_in_flight_keeps_order_and_surfaces_errors():
 
     with pytest.raises(ValueError):
         list(pl.in_flight(['A', 'B'], 6, bad))
+
+
+def _merge_run(tmp, feats, spec, monkeypatch, tag):
+    """-m m over a hand-made recipe on the C oracle engine; spec=False switches the look-ahead off."""
+    from oracle.c_engine import COracleEngine
+    cli = pkg('cli')
+    cd = pkg('change_detection')
+    os.makedirs(os.path.join(tmp, 'fea'), exist_ok=True)
+    synth.write_fea(os.path.join(tmp, 'fea', 'f.fea'), feats)
+    lines = []
+    t = 0.0
+    for k in range(24):
+        lines.append('audio=f.wav lna=a_%d start-time=%s end-time=%s speaker=spk_turn\n' % (k + 1, t, t + 3.0))
+        t += 3.5
+    rec = os.path.join(tmp, 'in.recipe')
+    with open(rec, 'w') as fh:
+        fh.writelines(lines)
+    if not spec:
+        monkeypatch.setattr(cd.ChangeDetectionRun, '_merge_speculate', lambda self, recipe, l, n: {})
+    out = os.path.join(tmp, tag + '.recipe')
+    if os.path.exists(out):
+        os.remove(out)
+    said = io.StringIO()
+    err = None
+    try:
+        cli.main_change_detection([rec, os.path.join(tmp, 'fea'), '-o', out, '-m', 'm', '-d', 'BIC', '-l', '1.3', '-tt'],
+                                  engine=COracleEngine(), stdout=said)
+    except ValueError as e:
+        err = str(e)
+    monkeypatch.undo()
+    return (open(out).read() if os.path.exists(out) else None), said.getvalue(), err
+
+
+def test_merge_mode_look_ahead_changes_nothing(tmp_path, monkeypatch):
+    """Merge mode takes the terms of every adjacent pair of recipe lines in one engine call and
+    goes back for single pairs only behind a merge (change_detection._merge_speculate): same
+    lines, same printed distances as one call per decision -- on clean frames, and on frames
+    with a NaN in a late line, where the reference raises AT the offending pair after the
+    earlier lines were written (the look-ahead then stands down)."""
+    feats, _, _ = synth.make_session(909, 90, 3)
+    ref = _merge_run(str(tmp_path / 'a'), feats, False, monkeypatch, 'out')
+    got = _merge_run(str(tmp_path / 'a'), feats, True, monkeypatch, 'out')
+    assert got == ref and ref[2] is None
+    assert ref[0].count('\n') < 24                  # some lines were merged: the single calls ran too
+    bad = feats.copy()
+    bad[int(60.0 * 125) + 10, 3] = np.nan           # inside line 18
+    ref = _merge_run(str(tmp_path / 'c'), bad, False, monkeypatch, 'out')
+    got = _merge_run(str(tmp_path / 'c'), bad, True, monkeypatch, 'out')
+    assert ref[2] is not None and 'infs or NaNs' in ref[2]
+    assert got == ref
