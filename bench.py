@@ -726,8 +726,9 @@ def host_driven_modes(args, synth, first_host, local):
         out['error'] = repr(e)[-300:]
     finally:
         eng.close()
-    out['note'] = ('in-process runs of the drop-in drivers on a 1 h file (.fea read + upload inside): every decision of '
-                   'these modes is a library call and a synchronisation, the serial chain is the reference\'s own')
+    out['note'] = ('in-process runs of the drop-in drivers on a 1 h file (.fea read + upload inside): merge mode takes the '
+                   'terms of all adjacent pairs in one call and goes back to the device only behind a merge; '
+                   'spk_cluster_in is one device-resident chain (spkd_cluster_in), replayed on the host')
     return out
 
 

@@ -123,6 +123,23 @@ spkd_status spkd_pair_terms(spkd_ctx *ctx, const double *d_stats,
 spkd_status spkd_distance_matrix(spkd_ctx *ctx, int kind, double lambdac,
                                  const double *d_stats, int64_t n, double *d_matrix);
 
+/* spk_cluster_in (spk-clustering.py:136-175, spk-clustering2.py:135-170) over n statistics
+ * records in recipe order, as one device-resident chain: record 0 founds cluster 0; every
+ * later record is compared with every cluster so far (the cluster is the distance's first
+ * argument, the record its second; a cluster's record is the sum of its members') and joins
+ * the first arg-min over the finite distances if that is <= threshold, else founds a cluster.
+ * kind: SPKD_BIC or SPKD_GLR.  h_label[n]: 0-based cluster of every record.  h_dist
+ * [dist_cap]: all distances in evaluation order, those of record s at h_dist_off[s] ..
+ * h_dist_off[s + 1] (h_dist_off[n + 1]) -- the caller replays the reference's prints and
+ * statistics from them.  *h_n_done: records processed; < n with SPKD_ENONFINITE (a
+ * covariance with infs or NaNs at record *h_n_done: the reference raises there, after the
+ * lines before it were written) or SPKD_EOVERFLOW (dist_cap too small: call again with more;
+ * n (n - 1) / 2 always fits).  *h_n_clusters: clusters founded. */
+spkd_status spkd_cluster_in(spkd_ctx *ctx, const double *d_stats, int64_t n, int kind,
+                            double lambdac, double threshold, int32_t *h_label,
+                            double *h_dist, int64_t dist_cap, int64_t *h_dist_off,
+                            int64_t *h_n_done, int64_t *h_n_clusters);
+
 /* Rows [row_begin, row_end) of that matrix, as spk_cluster_hi's variant `variant` fills them
  * (a block of the outer loop of spk-clustering.py:188-200 / spk-clustering2.py:178-184):
  * d_rows[(a - row_begin) * n + c] for c > a is the distance, c == a the diagonal value

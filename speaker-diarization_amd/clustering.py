@@ -69,7 +69,15 @@ class ClusteringRun(object):
         o = self.o
         rate = o.rate
         this_wav = ''
+        first = 0
+        if (o.method == 'in' and hasattr(self.eng, 'cluster_in') and o.distance in ('BIC', 'GLR')
+                and len(recipe) > 1 and all(rl[0] == recipe[0][0] for rl in recipe)):
+            # one file, a distance the device chain knows: the whole decision chain in one call
+            this_wav = recipe[0][0]
+            first = self._cluster_in_chain(recipe, writer)
         for l, rl in enumerate(recipe):
+            if l < first:
+                continue
             if rl[0] != this_wav:
                 this_wav = rl[0]
                 self._load(rl)
@@ -98,6 +106,46 @@ class ClusteringRun(object):
         return t.kl2
 
     # ----------------------------------------------------------------- in-order
+    def _cluster_in_chain(self, recipe, writer):
+        """CL1:136-175 / CL2:135-170 for a whole one-file recipe: the decisions are taken on the
+        device (engine.cluster_in), the reference's prints, statistics, speaker lists and recipe
+        lines are replayed from the returned distances and labels.  Returns the number of lines
+        done (fewer than all: a non-finite covariance -- the per-line path takes over there and
+        raises where the reference does)."""
+        o = self.o
+        rate = o.rate
+        self._load(recipe[0])
+        segs = [self._frames(rl[2] * rate, rl[3] * rate) for rl in recipe]
+        labels, dists, done = self.eng.cluster_in(segs, o.distance, o.lambdac, o.threshold)
+        for l in range(done):
+            rl = recipe[l]
+            if l == 0:
+                self.speakers.append([(rl[2] * rate, rl[3] * rate)])
+                writer.write(rl, rl[2] * rate, rl[3] * rate, 0, 'speaker_' + str(len(self.speakers)))
+                continue
+            if o.variant == 1:
+                start, end = int(rl[2] * rate), int(rl[3] * rate)
+            else:
+                start, end = rl[2] * rate, rl[3] * rate
+            for k, d in enumerate(dists[l]):
+                d = float(d)
+                if o.tt:
+                    self.say('Time:', end, '- Distance:', d, '- Speaker:', k + 1)
+                if not _isinf(d):
+                    if d > self.max_dist:
+                        self.max_dist = d
+                    if d < self.min_dist:
+                        self.min_dist = d
+            best = int(labels[l])
+            if best < len(self.speakers):
+                self.speakers[best].append((start, end))
+                writer.write(rl, start, end, 0, 'speaker_' + str(best + 1))
+            else:
+                self.speakers.append([(start, end)])
+                writer.write(rl, start, end, 0, 'speaker_' + str(len(self.speakers)))
+        self._spk_sets = None
+        return done
+
     def _cluster_in(self, rl, writer):
         """CL1:136-175 / CL2:135-170."""
         o = self.o

@@ -1949,4 +1949,113 @@ __global__ __launch_bounds__(AHC_TPB) void k_step_final(
     }
 }
 
+// ---------------------------------------------------------------------------
+// spk_cluster_in (spk-clustering.py:136-175 / spk-clustering2.py:135-170) as ONE device-resident
+// chain over the statistics records of the recipe's lines, in recipe order: record 0 founds
+// cluster 0; every later record is compared with every cluster so far -- the cluster is the
+// first argument of the distance, the new segment the second -- and joins the first arg-min
+// over the finite distances if that is <= threshold, else founds a new cluster.  A cluster's
+// record is the sum of its members' (the reference concatenates their frames); BIC's own term
+// of a grown cluster is the union determinant of the pair that grew it, GLR's takes one more
+// pass.  One workgroup: the chain is serial, a step is one wave pass for up to 16 clusters.
+// Host-driven (a library call and a synchronisation per segment and per stage) the same took
+// 345 us per segment; this takes ~10.
+// dist: all distances in evaluation order, dist_off[s] .. dist_off[s + 1] those of record s
+// (the host replays the reference's prints and statistics from them).  done[0]: records
+// processed (< n: a non-finite covariance or a full dist buffer stopped the chain at that
+// record), done[1]: clusters.
+// ---------------------------------------------------------------------------
+constexpr int CIN_WAVES = 4;
+constexpr int CIN_TPB = CIN_WAVES * WAVE;
+
+template <bool TWO>
+__global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
+        const double* __restrict__ seg_ex, const double* __restrict__ seg_pk, const double* __restrict__ seg_ld,
+        long long n, int kind, double lambdac, double threshold,
+        double* __restrict__ clu_ex, double* __restrict__ clu_pk, double* __restrict__ clu_ld,
+        double* __restrict__ tmp, int32_t* __restrict__ label, double* __restrict__ dist, long long dist_cap,
+        long long* __restrict__ dist_off, long long* __restrict__ done, int* err) {
+    __shared__ double ldsA[QREC];
+    __shared__ int s_best, s_stop;
+    __shared__ double s_mind;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const QuadLane L = quad_lane();
+    for (int e = tid; e < QREC; e += CIN_TPB) clu_ex[e] = seg_ex[e];
+    for (int e = tid; e < REC; e += CIN_TPB) clu_pk[e] = seg_pk[e];
+    if (tid == 0) { clu_ld[0] = seg_ld[0]; label[0] = 0; dist_off[0] = 0; dist_off[1] = 0; }
+    long long K = 1, off = 0, s = 1;
+    __syncthreads();
+    for (; s < n; ++s) {
+        const double* A = seg_ex + s * QREC;
+        stage_record(ldsA, A, tid, CIN_TPB);
+        __syncthreads();
+        const double nA = ldsA[QREC_COUNT_AT], ldS = seg_ld[s];
+        for (long long base = 4 * wave; base < K; base += 4 * CIN_WAVES) {
+            const long long k = base + L.m;
+            const bool valid = k < K;
+            const long long kk = valid ? k : K - 1;
+            const double v = quad_pair_det<TWO>(kind, ldsA, nA, A, clu_ex + kk * QREC, clu_pk + kk * REC, false, L, err);
+            if (valid && L.t == 0) tmp[k] = v;
+        }
+        __syncthreads();
+        const bool room = off + K <= dist_cap;
+        for (long long k = tid; k < K && room; k += CIN_TPB) {
+            const double ldx = log(tmp[k]);
+            tmp[k] = ldx;
+            dist[off + k] = finish_distance(kind, lambdac, clu_pk[k * REC + REC - 1], clu_ld[k], nA, ldS, ldx);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double mind = MAXINT_F;                      // sys.maxint
+            int best = -1;
+            for (long long k = 0; k < K && room; ++k) {
+                const double d = dist[off + k];
+                // "if d != inf and d != -inf" (a NaN passes and then fails every comparison)
+                if (d != __builtin_huge_val() && d != -__builtin_huge_val() && d < mind) { mind = d; best = (int)k; }
+            }
+            s_mind = mind; s_best = best;
+            int stop = room ? 0 : 1;
+            if (!room) atomicOr(err, 4);                 // the host gave too small a buffer
+            if (*reinterpret_cast<volatile int*>(err) & ERR_NONFINITE) stop = 1;
+            s_stop = stop;
+        }
+        __syncthreads();
+        if (s_stop) break;
+        const int best = s_best;
+        if (s_mind <= threshold && best >= 0) {
+            double* Cx = clu_ex + (long long)best * QREC;
+            double* Cp = clu_pk + (long long)best * REC;
+            const double* Sp = seg_pk + s * REC;
+            for (int e = tid; e < QREC; e += CIN_TPB) {
+                const double m = Cx[e] + ldsA[e];
+                Cx[e] = m;
+                ldsA[e] = m;
+            }
+            for (int e = tid; e < REC; e += CIN_TPB) Cp[e] = Cp[e] + Sp[e];
+            __syncthreads();
+            if (TWO && kind == SPKD_GLR) {
+                if (wave == 0) {
+                    const double v = quad_pair_det<TWO>(kind, ldsA, ldsA[QREC_COUNT_AT], Cx, Cx, Cp, true, L, err);
+                    if (lane == 0) clu_ld[best] = log(v);
+                }
+            } else if (tid == 0) {
+                clu_ld[best] = tmp[best];                // the union of the pair IS the grown cluster
+            }
+            if (tid == 0) label[s] = best;
+        } else {
+            double* Cx = clu_ex + K * QREC;
+            double* Cp = clu_pk + K * REC;
+            const double* Sp = seg_pk + s * REC;
+            for (int e = tid; e < QREC; e += CIN_TPB) Cx[e] = ldsA[e];
+            for (int e = tid; e < REC; e += CIN_TPB) Cp[e] = Sp[e];
+            if (tid == 0) { clu_ld[K] = ldS; label[s] = (int32_t)K; }
+        }
+        off += K;
+        if (!(s_mind <= threshold && best >= 0)) ++K;
+        if (tid == 0) dist_off[s + 1] = off;
+        __syncthreads();
+    }
+    if (tid == 0) { done[0] = s; done[1] = K; }
+}
+
 }  // namespace spkd

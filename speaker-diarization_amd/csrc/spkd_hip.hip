@@ -518,6 +518,64 @@ spkd_status spkd_distance_matrix(spkd_ctx* c, int kind, double lambdac, const do
     return end_call(c);
 }
 
+spkd_status spkd_cluster_in(spkd_ctx* c, const double* d_stats, int64_t n, int kind, double lambdac, double threshold,
+                            int32_t* h_label, double* h_dist, int64_t dist_cap, int64_t* h_dist_off,
+                            int64_t* h_n_done, int64_t* h_n_clusters) {
+    if (!c || n < 0 || dist_cap < 0 || (kind != SPKD_BIC && kind != SPKD_GLR)) return SPKD_EINVAL;
+    if (h_n_done) *h_n_done = 0;
+    if (h_n_clusters) *h_n_clusters = 0;
+    if (n == 0) return SPKD_OK;
+    if (!d_stats || !h_label || !h_dist_off || !h_n_done || !h_n_clusters || (dist_cap > 0 && !h_dist))
+        return fail(c, SPKD_EINVAL, "null argument");
+    spkd_status st = begin_call(c);
+    if (st != SPKD_OK) return st;
+    void *p_ex = nullptr, *p_ld = nullptr, *p_aux = nullptr, *p_cex = nullptr, *p_cpk = nullptr, *p_misc = nullptr, *p_dist = nullptr;
+    const size_t nn = (size_t)n;
+    if ((st = scratch(c, S_AHC_STATS, nn * QREC * sizeof(double), &p_ex)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_AHC_LD, nn * sizeof(double), &p_ld)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_AHC_AUX, nn * AUX * sizeof(double), &p_aux)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_STEP_EXM, nn * QREC * sizeof(double), &p_cex)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_STEP_PKM, nn * REC * sizeof(double), &p_cpk)) != SPKD_OK) return st;
+    // misc: cluster log dets | determinants of a step | dist_off | done | labels
+    const size_t misc_bytes = 2 * nn * sizeof(double) + (nn + 1 + 2) * sizeof(long long) + nn * sizeof(int32_t) + 64;
+    if ((st = scratch(c, S_STEP_MISC, misc_bytes, &p_misc)) != SPKD_OK) return st;
+    if ((st = scratch(c, S_AHC_MAT, (size_t)std::max<int64_t>(dist_cap, 1) * sizeof(double), &p_dist)) != SPKD_OK) return st;
+    double* clu_ld = (double*)p_misc;
+    double* tmp = clu_ld + nn;
+    long long* d_off = (long long*)(tmp + nn);
+    long long* d_done = d_off + nn + 1;
+    int32_t* d_label = (int32_t*)(d_done + 2);
+    HIPCHK(c, hipMemsetAsync(d_done, 0, 2 * sizeof(long long), c->stream));
+    // the records in the quad layout, their own log dets (four records per wave)
+    hipLaunchKernelGGL(k_to_quadrec, dim3((unsigned)n), dim3(256), 0, c->stream, d_stats, n, (double*)p_ex);
+    {
+        const int64_t per_block = 4 * PT_WAVES;
+        const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+        TIMED(c, SPKD_T_CLUSTER_PREP,
+              hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
+                                 (const double*)p_ex, n, kind, (double*)p_ld, (double*)p_aux, c->d_err));
+    }
+    auto kin = kind == SPKD_GLR ? k_cluster_in<true> : k_cluster_in<false>;
+    (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
+    hipLaunchKernelGGL(kin, dim3(1), dim3(CIN_TPB), 0, c->stream,
+                       (const double*)p_ex, d_stats, (const double*)p_ld, (long long)n, kind, lambdac, threshold,
+                       (double*)p_cex, (double*)p_cpk, clu_ld, tmp, d_label, (double*)p_dist, (long long)dist_cap,
+                       d_off, d_done, c->d_err);
+    (void)hipEventRecord(c->kb[SPKD_T_AHC], c->stream);
+    c->kused[SPKD_T_AHC] = true;
+    HIPCHK(c, hipGetLastError());
+    long long done2[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(done2, d_done, sizeof done2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_label, d_label, nn * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_dist_off, d_off, (nn + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    if (dist_cap > 0)
+        HIPCHK(c, hipMemcpyAsync(h_dist, p_dist, (size_t)dist_cap * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    st = end_call(c);
+    *h_n_done = done2[0];
+    *h_n_clusters = done2[1];
+    return st;
+}
+
 spkd_status spkd_distance_rows(spkd_ctx* c, int variant, int kind, double lambdac, const double* d_stats,
                                int64_t n, int64_t row_begin, int64_t row_end, double* d_rows,
                                double* h_stat_max, double* h_stat_min) {

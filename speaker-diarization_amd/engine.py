@@ -149,6 +149,18 @@ class HipEngine(object):
                                  _f(row[6]) if want_kl2 else None))
         return res
 
+    def cluster_in(self, segs, kind, lambdac, threshold):
+        """spk_cluster_in over the segments `segs` (frame ranges, recipe order) as one device
+        chain (spkd_cluster_in): (labels, distances per segment, segments done).  done < len(segs):
+        a covariance with infs or NaNs at segment `done` -- the caller goes on from there the slow
+        way, which raises where the reference does."""
+        d = self._stats_of_sets([[s] for s in segs])
+        try:
+            label, dists, done, _, _ = self.ctx.cluster_in(d, len(segs), kind, lambdac, threshold)
+        finally:
+            self.ctx.dev_free(d)
+        return label, dists, done
+
     # ------------------------------------------------------------- growing window
     def gw(self, turns, kind, lambdac, threshold, winsize, winstep, deltaws, rate, trace=False):
         p = hipabi.CdParams(hipabi.KINDS[kind], 1 if trace else 0, lambdac, threshold, winsize,

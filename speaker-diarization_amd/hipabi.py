@@ -21,7 +21,7 @@ EXPORTS = ['spkd_abi_version', 'spkd_create', 'spkd_create_on_stream', 'spkd_des
            'spkd_malloc', 'spkd_free', 'spkd_memcpy_h2d', 'spkd_memcpy_d2h', 'spkd_memcpy_d2d',
            'spkd_last_kernel_ms', 'spkd_last_gw_items', 'spkd_set_stats', 'spkd_pair_terms',
            'spkd_distance_matrix', 'spkd_gw_event_capacity', 'spkd_gw_event_capacity_p', 'spkd_gw', 'spkd_gw_ex', 'spkd_gw_fused', 'spkd_gather_stats', 'spkd_mfcc',
-           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_ahc_matrix', 'spkd_distance_rows', 'spkd_py2_roundtrip',
+           'spkd_sw_window_count', 'spkd_sw', 'spkd_ahc', 'spkd_ahc_matrix', 'spkd_distance_rows', 'spkd_cluster_in', 'spkd_py2_roundtrip',
            'spkd_labels_from_merges', 'spkd_labels_from_merges_batch', 'spkd_count_flags', 'spkd_gw_lines']
 
 
@@ -165,6 +165,7 @@ def load_library(path=None):
     lib.spkd_ahc.argtypes = [vp, vp, vp, i64, P(AhcParams), vp, vp, vp, vp, vp, vp]
     lib.spkd_ahc_matrix.argtypes = [vp, vp, i64, P(AhcParams), vp, dbl, dbl, vp, vp, vp, vp, vp, vp]
     lib.spkd_distance_rows.argtypes = [vp, C.c_int, C.c_int, dbl, vp, i64, i64, i64, vp, P(dbl), P(dbl)]
+    lib.spkd_cluster_in.argtypes = [vp, vp, i64, C.c_int, dbl, dbl, vp, vp, i64, vp, P(i64), P(i64)]
     lib.spkd_py2_roundtrip.argtypes = [vp, i64]
     lib.spkd_py2_roundtrip.restype = None
     lib.spkd_labels_from_merges.argtypes = [i64, i64, vp, vp, vp]
@@ -503,6 +504,30 @@ class Context(object):
         if st == SPKD_ENONFINITE:
             raise ValueError('array must not contain infs or NaNs')
         return smax.value, smin.value
+
+    def cluster_in(self, d_stats, n, kind, lambdac, threshold):
+        """spk_cluster_in over n records in recipe order as one device chain -> (labels[n],
+        per-record distance lists (done records only), records done, clusters, status).  status is
+        SPKD_ENONFINITE when a covariance with infs or NaNs stopped the chain at record `done`."""
+        n = int(n)
+        label = np.zeros(max(n, 1), dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.int64)
+        done, nclu = C.c_int64(0), C.c_int64(0)
+        full = n * (n - 1) // 2
+        cap = min(full, 32 * n)
+        while True:
+            dist = np.empty(max(cap, 1), dtype=np.float64)
+            st = self.lib.spkd_cluster_in(self.h, C.c_void_p(d_stats), n, KINDS[kind] if isinstance(kind, str) else int(kind),
+                                          float(lambdac), float(threshold), _ptr(label), _ptr(dist), cap, _ptr(off),
+                                          C.byref(done), C.byref(nclu))
+            if st == SPKD_EOVERFLOW and cap < full:
+                cap = min(full, 4 * cap)
+                continue
+            break
+        self.check(st, allow=(SPKD_ENONFINITE,))
+        nd = int(done.value)
+        dists = [dist[int(off[s]):int(off[s + 1])].copy() for s in range(nd)]
+        return label[:n], dists, nd, int(nclu.value), st
 
     def ahc_matrix(self, d_stats, n, params, d_matrix, stat_max_in=float('nan'), stat_min_in=float('nan')):
         """The merge loop of one n-record problem on a caller-supplied initial matrix."""

@@ -467,3 +467,74 @@ def test_pair_terms_record_cache_is_transparent(eng):
                      for x in t)
     assert [bits(t) for t in cold] == [bits(t) for t in warm]
     assert [bits(t) for t in cold[:len(jobs)]] == [bits(t) for t in tiny]
+
+
+class _NoChain(object):
+    """An engine without the device chain of spk_cluster_in: the drivers fall back to one call per line."""
+
+    def __init__(self, eng):
+        self._eng = eng
+
+    def __getattr__(self, name):
+        if name == 'cluster_in':
+            raise AttributeError(name)
+        return getattr(self._eng, name)
+
+
+def _in_mode(tmp, engine, variant, extra):
+    import io
+    cli = pkg('cli')
+    out = os.path.join(tmp, 'in.recipe')
+    if os.path.exists(out):
+        os.remove(out)
+    said = io.StringIO()
+    err = None
+    try:
+        cli.main_clustering([os.path.join(tmp, 'spkc.recipe'), os.path.join(tmp, 'fea') + '/', '-o', out, '-m', 'in'] + extra,
+                            variant=variant, engine=engine, stdout=said)
+    except ValueError as e:
+        err = str(e)
+    return (open(out).read() if os.path.exists(out) else None), said.getvalue(), err
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+def test_cluster_in_device_chain_equals_the_per_line_path(eng, variant, tmp_path):
+    """spk_cluster_in as one device-resident chain (spkd_cluster_in: clusters as sums of their
+    members' records, the decisions on the device, prints and statistics replayed on the host)
+    against the same mode driven line by line (statistics of every cluster from its frames, one
+    library call per line) and against the C oracle: same recipe lines, same summary, printed
+    distances to 1e-9 -- BIC and GLR, a threshold that founds a cluster per line (the distance
+    buffer's first guess overflows and is grown), and a NaN frame in a late line (the chain stops
+    there, the per-line path raises where the reference does)."""
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    tmp = str(tmp_path)
+    feats, _, truth = synth.make_session(515, 900, 4)
+    os.makedirs(os.path.join(tmp, 'fea'))
+    lines = ['audio=s.wav lna=a_%d start-time=%s end-time=%s speaker=spk_turn\n' % (k + 1, a / 125.0, b / 125.0)
+             for k, (a, b, _) in enumerate(truth)]
+    assert len(lines) > 70
+    with open(os.path.join(tmp, 'spkc.recipe'), 'w') as fh:
+        fh.writelines(lines)
+
+    def same(a, b, rel=1e-9):
+        assert a[0] == b[0] and a[2] == b[2]
+        assert_stdout_close(a[1], b[1], rel)
+
+    synth.write_fea(os.path.join(tmp, 'fea', 's.fea'), feats)
+    for extra in (['-l', '1.3', '-tt'], ['-d', 'GLR', '-t', '1800', '-tt'], ['-l', '1.3', '-t=-1e30']):
+        chain = _in_mode(tmp, eng, variant, extra)
+        slow = _in_mode(tmp, _NoChain(eng), variant, extra)
+        orc = _in_mode(tmp, COracleEngine(), variant, extra)
+        assert chain[2] is None and chain[0].count('\n') == len(lines)
+        same(chain, slow)
+        same(chain, orc)
+    assert len(set(re.findall(r'speaker=(\S+)', chain[0]))) == len(lines)          # the last run: a cluster per line
+    bad = feats.copy()
+    a, b, _ = truth[60]
+    bad[(a + b) // 2, 7] = np.nan
+    synth.write_fea(os.path.join(tmp, 'fea', 's.fea'), bad)
+    chain = _in_mode(tmp, eng, variant, ['-l', '1.3', '-tt'])
+    slow = _in_mode(tmp, _NoChain(eng), variant, ['-l', '1.3', '-tt'])
+    assert chain[2] is not None and 'infs or NaNs' in chain[2]
+    same(chain, slow)
