@@ -538,3 +538,36 @@ def test_cluster_in_device_chain_equals_the_per_line_path(eng, variant, tmp_path
     slow = _in_mode(tmp, _NoChain(eng), variant, ['-l', '1.3', '-tt'])
     assert chain[2] is not None and 'infs or NaNs' in chain[2]
     same(chain, slow)
+
+
+@pytest.mark.parametrize('kind', ['BIC', 'GLR'])
+def test_tiny_problems_through_every_chain(eng, kind):
+    """One to five segments: the hand-off-free merge chain (one launch per merge, a bookkeeper
+    workgroup beside the partners'), the one-workgroup merge loop and the spk_cluster_in chain
+    on problems smaller than a wave pass -- no merges at all, one partner, a forced merge down
+    to one speaker -- against the C oracle."""
+    from oracle.c_engine import COracleEngine
+    synth = pkg('synth')
+    hipabi = pkg('hipabi')
+    feats, _, truth = synth.make_session(7117, 120, 3)
+    eng.set_features(feats)
+    orc = COracleEngine()
+    orc.set_features(feats)
+    segs_all = [(a, b) for a, b, _ in truth]
+    thr = {'BIC': 0.0, 'GLR': 2500.0}[kind]
+    for n in (1, 2, 3, 5):
+        segs = segs_all[:n]
+        for max_spk in (0, 1):
+            want = orc.cluster_hi(segs, 1, kind, 1.3, thr, max_spk)
+            for path in (hipabi.AHC_MONO, hipabi.AHC_WIDE):
+                eng.ahc_path = path
+                try:
+                    got = eng.cluster_hi(segs, 1, kind, 1.3, thr, max_spk)
+                finally:
+                    eng.ahc_path = hipabi.AHC_AUTO
+                _same_merges(got.merges, want.merges)
+                if max_spk == 1 and n > 1:
+                    assert len(got.merges) == n - 1
+        label, dists, done = eng.cluster_in(segs, kind, 1.3, thr)
+        assert done == n and len(label) == n and int(label[0]) == 0
+        assert [len(d) for d in dists] == [0] + [len(set(int(x) for x in label[:s])) for s in range(1, n)]
