@@ -88,79 +88,6 @@ __device__ __forceinline__ void kl2_aux_from_cov(double (&a)[DA], double mean_i,
 // ---------------------------------------------------------------------------
 constexpr int PT_WAVES = 4;
 
-__global__ __launch_bounds__(PT_WAVES * WAVE) void k_pair_terms(
-        const double* __restrict__ stats, const int32_t* __restrict__ ia,
-        const int32_t* __restrict__ ib, int64_t n_pairs, int flags,
-        double* __restrict__ out, int* err) {
-    __shared__ double slabs[PT_WAVES][REC];
-    const int wave = threadIdx.x >> 6;
-    const int lane = lane_id();
-    const int64_t pair = (int64_t)blockIdx.x * PT_WAVES + wave;
-    if (pair >= n_pairs) return;
-    double* slab = slabs[wave];
-    const double* A = stats + (int64_t)ia[pair] * REC;
-    const double* B = stats + (int64_t)ib[pair] * REC;
-    const double n1 = A[REC - 1], n2 = B[REC - 1];
-    const double n = n1 + n2;
-    double res[4];
-    const int njobs = (flags & SPKD_WANT_GLR) ? 4 : 3;
-    double a[DA];
-#pragma unroll 1
-    for (int t = 0; t < njobs; ++t) {
-        auto form = [&](double (&q)[DA]) {
-            if (t < 3) {
-                if (t == 0) stage1(slab, A);
-                else if (t == 1) stage1(slab, B);
-                else stage2(slab, A, B, 1.0);
-                row_from_slab(slab, q);
-                cov_rows(q, t == 0 ? n1 : (t == 1 ? n2 : n));
-            } else {
-                // (n1/N) S1 + (n2/N) S2, linear in the moments
-                const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
-                const double be1 = al1 / n1, be2 = al2 / n2;
-                stage1(slab, A);
-                row_from_slab(slab, q);
-                const double s1i = q[D];
-#pragma unroll
-                for (int j = 0; j < D; ++j) q[j] *= al1;
-                stage1(slab, B);
-                double q2[DA];
-                row_from_slab(slab, q2);
-                const double s2i = q2[D];
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    const double s1j = readlane_d(s1i, j), s2j = readlane_d(s2i, j);
-                    double v = fma(al2, q2[j], q[j]);
-                    v = fma(-(be1 * s1i), s1j, v);
-                    q[j] = fma(-(be2 * s2i), s2j, v);
-                }
-            }
-        };
-        res[t] = logdet_formed(a, err, form);
-    }
-    double kl = __builtin_nan("");
-    if (flags & SPKD_WANT_KL2) {
-        double ds[2], dp[2], mu[2];
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {
-            stage1(slab, t ? B : A);
-            row_from_slab(slab, a);
-            const double nn = t ? n2 : n1;
-            const double mean_i = a[D] / nn;
-            cov_rows(a, nn);
-            kl2_lane_terms(a, mean_i, ds[t], dp[t], mu[t]);
-        }
-        kl = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
-    }
-    if (lane == 0) {
-        double* o = out + pair * 8;
-        o[0] = n1; o[1] = n2; o[2] = res[0]; o[3] = res[1]; o[4] = res[2];
-        o[5] = (flags & SPKD_WANT_GLR) ? res[3] : __builtin_nan("");
-        o[6] = kl; o[7] = 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Packed -> quad records (see spkd_quad.hpp).  The packed form (6 560 B) stays the
 // ABI format; the clustering kernels keep their working set as quad records.
 __global__ __launch_bounds__(256) void k_to_quadrec(const double* __restrict__ packed, int64_t n_rec,
@@ -343,6 +270,151 @@ __device__ __forceinline__ double quad_pair_det(int kind, const double* ldsA, do
 
 __device__ __forceinline__ void stage_record(double* lds, const double* __restrict__ g, int tid, int nthreads) {
     for (int e = tid; e < QREC; e += nthreads) lds[e] = g[e];
+}
+
+// ---------------------------------------------------------------------------
+// Pair terms for the host-driven modes (merge_rec, spk_cluster_in with KL2): per pair the four
+// log determinants a BIC or GLR distance is made of -- cov(A), cov(B), cov(A u B), and the
+// count-weighted mean covariance -- as ONE wave pass: the four matrices of a pair are the four
+// DPP rows of the quad elimination, all formed from A's record (staged in LDS in the quad
+// layout) and B's (loaded like any partner record) with a row's own weights:
+//     M = wa A + wc B + w1 v1 v1' + w2 v2 v2',   v1 = k1a s_A + k1c s_B,  v2 = k2a s_A + k2c s_B
+//   row 0  cov(A):      wa = 1/(n1-1), wc = 0,        v1 = s_A,       w1 = -wa/n1
+//   row 1  cov(B):      wa = 0,        wc = 1/(n2-1), v1 = s_B,       w1 = -wc/n2
+//   row 2  cov(A u B):  wa = wc = 1/(n-1),            v1 = s_A + s_B, w1 = -wa/n
+//   row 3  GLR:         wa = (n1/n)/(n1-1), wc = (n2/n)/(n2-1), v1 = s_A, w1 = -wa/n1,
+//                       v2 = s_B, w2 = -wc/n2     (without SPKD_WANT_GLR: row 2 again)
+// A matrix that meets a pivot that is not a positive finite number is redone with partial
+// pivoting in the row-per-lane layout (tri_det), the definition the clustering kernels use.
+// Until round 3 this kernel did the determinants one after the other in the row-per-lane
+// layout (342 VGPRs, scratch): the last of its kind.  KL2 (pseudo-inverse diagonals) is
+// row-per-lane work by nature and stays so.
+// Two waves per workgroup, a pair each: A's and B's quad copies in LDS (2 x 10 KB a wave).
+// ---------------------------------------------------------------------------
+constexpr int PT2_WAVES = 2;
+
+// the 81 loads of a partner record (packed layout) into the elimination's registers, as
+// quad_pair_det issues them (one base pointer per 4 KB of the record)
+__device__ __forceinline__ void quad_load_packed(const double* __restrict__ pkC, int ta, QuadRows& q, double (&sc)[QS]) {
+    const int t12 = ta < QL ? ta : QL - 1;          // idle lanes 13..15 ride with lane 12
+    const double* rt[2];
+    long long o1 = 512;                 // opaque, so that the bases stay separate registers
+    asm volatile("" : "+v"(o1));
+    rt[0] = pkC + t12;
+    rt[1] = rt[0] + o1;
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < tri_cols(s); ++j) {
+            const int e = pk_off(j) + QL * s - j;   // + t12 (in the base)
+            q.r[s][j] = rt[e / 512][e % 512];
+        }
+        const int c = QL * s + t12;                 // this lane's row of slot s
+        sc[s] = pkC[pk_off(c) + D - c];             // (39, c): the sums entry of column c
+    }
+}
+
+__device__ __forceinline__ void quad_from_packed_lds(double* lds, const double* __restrict__ g, int lane) {
+    for (int e = lane; e < QREC; e += WAVE) {             // (k_to_quadrec's map, by one wave)
+        const int t = e & 15, sj = e >> 4;
+        const int s = sj / DA, j = sj - s * DA;
+        double v = 0.0;
+        if (t < QL) {
+            const int i = QL * s + t;
+            const int r = i < j ? i : j, cc = i < j ? j : i;
+            v = g[pk(r, cc)];
+        } else if (e == QREC_COUNT_AT) {
+            v = g[REC - 1];
+        }
+        lds[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(PT2_WAVES * WAVE) void k_pair_terms(
+        const double* __restrict__ stats, const int32_t* __restrict__ ia,
+        const int32_t* __restrict__ ib, int64_t n_pairs, int flags,
+        double* __restrict__ out, int* err) {
+    __shared__ double slabs[PT2_WAVES][2][QREC];
+    const int wave = threadIdx.x >> 6;
+    const int lane = lane_id();
+    const int64_t pair = (int64_t)blockIdx.x * PT2_WAVES + wave;
+    if (pair >= n_pairs) return;                           // (whole waves: no workgroup barrier below)
+    double* ldsA = slabs[wave][0];
+    double* ldsB = slabs[wave][1];
+    const double* A = stats + (int64_t)ia[pair] * REC;
+    const double* B = stats + (int64_t)ib[pair] * REC;
+    const double n1 = A[REC - 1], n2 = B[REC - 1];
+    const double n = n1 + n2;
+    const QuadLane L = quad_lane();
+    int ta = L.t;
+    asm volatile("" : "+v"(ta));
+    QuadRows q;
+    double sc[QS];
+    quad_load_packed(B, ta, q, sc);                        // (in flight while the quad copies are made)
+    quad_from_packed_lds(ldsA, A, lane);
+    quad_from_packed_lds(ldsB, B, lane);
+    // this row's weights
+    const bool want_glr = (flags & SPKD_WANT_GLR) != 0;
+    const int mode = (L.m == 3 && !want_glr) ? 2 : L.m;
+    double wa, wc, k1a, k1c, w1, k2c, w2;
+    {
+        const double fA = 1.0 / (n1 - 1.0), fB = 1.0 / (n2 - 1.0), fU = 1.0 / (n - 1.0);
+        const double al1 = (n1 / n) / (n1 - 1.0), al2 = (n2 / n) / (n2 - 1.0);
+        wa = mode == 0 ? fA : (mode == 1 ? 0.0 : (mode == 2 ? fU : al1));
+        wc = mode == 0 ? 0.0 : (mode == 1 ? fB : (mode == 2 ? fU : al2));
+        k1a = mode == 1 ? 0.0 : 1.0;
+        k1c = (mode == 1 || mode == 2) ? 1.0 : 0.0;
+        w1 = mode == 0 ? -(fA / n1) : (mode == 1 ? -(fB / n2) : (mode == 2 ? -(fU / n) : -(al1 / n1)));
+        k2c = mode == 3 ? 1.0 : 0.0;
+        w2 = mode == 3 ? -(al2 / n2) : 0.0;
+    }
+    double v1[QS], v2[QS], c1[QS], c2[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+#pragma unroll
+        for (int j = 0; j < tri_cols(s); ++j)
+            q.r[s][j] = fma(wa, ldsA[(s * DA + j) * 16 + ta], wc * q.r[s][j]);
+        const double sa = ldsA[(s * DA + D) * 16 + ta];
+        v1[s] = fma(k1c, sc[s], k1a * sa);
+        v2[s] = k2c * sc[s];
+        c1[s] = w1 * v1[s];
+        c2[s] = w2 * v2[s];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    TriRank1<0>::run(q, c1, v1);
+    TriRank1<0>::run(q, c2, v2);
+    auto form_single = [&](int mi, double (&a)[DA]) {
+        const int md = (mi == 3 && !want_glr) ? 2 : mi;
+        if (md == 0) single_pair_matrix(SPKD_BIC, ldsA, ldsA, true, a);
+        else if (md == 1) single_pair_matrix(SPKD_BIC, ldsB, ldsB, true, a);
+        else single_pair_matrix(md == 2 ? SPKD_BIC : SPKD_GLR, ldsA, ldsB, false, a);
+    };
+    const double ld = log(tri_det(q, L.m, err, form_single));
+    double res[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) res[mi] = __shfl(ld, 16 * mi);
+    double kl = __builtin_nan("");
+    if (flags & SPKD_WANT_KL2) {
+        double* slab = ldsA;                               // (REC <= QREC; the quad copies are done with)
+        double a[DA];
+        double ds[2], dp[2], mu[2];
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            stage1(slab, t ? B : A);
+            row_from_slab(slab, a);
+            const double nn = t ? n2 : n1;
+            const double mean_i = a[D] / nn;
+            cov_rows(a, nn);
+            kl2_lane_terms(a, mean_i, ds[t], dp[t], mu[t]);
+        }
+        kl = kl2_combine(ds[0], dp[0], mu[0], ds[1], dp[1], mu[1]);
+    }
+    if (lane == 0) {
+        double* o = out + pair * 8;
+        o[0] = n1; o[1] = n2; o[2] = res[0]; o[3] = res[1]; o[4] = res[2];
+        o[5] = want_glr ? res[3] : __builtin_nan("");
+        o[6] = kl; o[7] = 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------

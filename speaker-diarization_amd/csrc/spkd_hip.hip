@@ -339,9 +339,9 @@ spkd_status spkd_pair_terms(spkd_ctx* c, const double* d_stats, const int32_t* h
     if ((st = upload(c, S_IDXA, va, &d_a)) != SPKD_OK) return st;
     if ((st = upload(c, S_IDXB, vb, &d_b)) != SPKD_OK) return st;
     if ((st = scratch(c, S_TERMS, (size_t)n_pairs * 8 * sizeof(double), &d_terms)) != SPKD_OK) return st;
-    const unsigned blocks = (unsigned)((n_pairs + PT_WAVES - 1) / PT_WAVES);
+    const unsigned blocks = (unsigned)((n_pairs + PT2_WAVES - 1) / PT2_WAVES);
     TIMED(c, SPKD_T_PAIR_TERMS,
-          hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
+          hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(PT2_WAVES * WAVE), 0, c->stream,
                              d_stats, d_a, d_b, n_pairs, flags, (double*)d_terms, c->d_err));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_terms, d_terms, (size_t)n_pairs * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
