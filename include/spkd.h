@@ -128,7 +128,7 @@ spkd_status spkd_distance_matrix(spkd_ctx *ctx, int kind, double lambdac,
  * later record is compared with every cluster so far (the cluster is the distance's first
  * argument, the record its second; a cluster's record is the sum of its members') and joins
  * the first arg-min over the finite distances if that is <= threshold, else founds a cluster.
- * kind: SPKD_BIC or SPKD_GLR.  h_label[n]: 0-based cluster of every record.  h_dist
+ * kind: SPKD_BIC, SPKD_GLR or SPKD_KL2.  h_label[n]: 0-based cluster of every record.  h_dist
  * [dist_cap]: all distances in evaluation order, those of record s at h_dist_off[s] ..
  * h_dist_off[s + 1] (h_dist_off[n + 1]) -- the caller replays the reference's prints and
  * statistics from them.  *h_n_done: records processed; < n with SPKD_ENONFINITE (a

@@ -70,7 +70,7 @@ class ClusteringRun(object):
         rate = o.rate
         this_wav = ''
         first = 0
-        if (o.method == 'in' and hasattr(self.eng, 'cluster_in') and o.distance in ('BIC', 'GLR')
+        if (o.method == 'in' and hasattr(self.eng, 'cluster_in')
                 and len(recipe) > 1 and all(rl[0] == recipe[0][0] for rl in recipe)):
             # one file, a distance the device chain knows: the whole decision chain in one call
             this_wav = recipe[0][0]

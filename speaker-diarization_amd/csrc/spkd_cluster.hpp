@@ -2043,8 +2043,8 @@ constexpr int CIN_TPB = CIN_WAVES * WAVE;
 template <bool TWO>
 __global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
         const double* __restrict__ seg_ex, const double* __restrict__ seg_pk, const double* __restrict__ seg_ld,
-        long long n, int kind, double lambdac, double threshold,
-        double* __restrict__ clu_ex, double* __restrict__ clu_pk, double* __restrict__ clu_ld,
+        const double* __restrict__ seg_aux, long long n, int kind, double lambdac, double threshold,
+        double* __restrict__ clu_ex, double* __restrict__ clu_pk, double* __restrict__ clu_ld, double* __restrict__ clu_aux,
         double* __restrict__ tmp, int32_t* __restrict__ label, double* __restrict__ dist, long long dist_cap,
         long long* __restrict__ dist_off, long long* __restrict__ done, int* err) {
     __shared__ double ldsA[QREC];
@@ -2055,6 +2055,8 @@ __global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
     for (int e = tid; e < QREC; e += CIN_TPB) clu_ex[e] = seg_ex[e];
     for (int e = tid; e < REC; e += CIN_TPB) clu_pk[e] = seg_pk[e];
     if (tid == 0) { clu_ld[0] = seg_ld[0]; label[0] = 0; dist_off[0] = 0; dist_off[1] = 0; }
+    const bool kl2 = kind == SPKD_KL2;               // distances from the records' KL2 vectors (k_cluster_prep), no eliminations
+    if (kl2) for (int e = tid; e < AUX; e += CIN_TPB) clu_aux[e] = seg_aux[e];
     long long K = 1, off = 0, s = 1;
     __syncthreads();
     for (; s < n; ++s) {
@@ -2062,7 +2064,7 @@ __global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
         stage_record(ldsA, A, tid, CIN_TPB);
         __syncthreads();
         const double nA = ldsA[QREC_COUNT_AT], ldS = seg_ld[s];
-        for (long long base = 4 * wave; base < K; base += 4 * CIN_WAVES) {
+        for (long long base = 4 * wave; base < K && !kl2; base += 4 * CIN_WAVES) {
             const long long k = base + L.m;
             const bool valid = k < K;
             const long long kk = valid ? k : K - 1;
@@ -2072,6 +2074,20 @@ __global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
         __syncthreads();
         const bool room = off + K <= dist_cap;
         for (long long k = tid; k < K && room; k += CIN_TPB) {
+            if (kl2) {
+                // (one lane per pair, 39-term sums done serially: the arithmetic of k_ahc's finish)
+                const double* a1 = clu_aux + k * AUX;
+                const double* a2 = seg_aux + s * AUX;
+                double t1 = 0.0, t2 = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    const float dm = (float)a1[2 * DA + i] - (float)a2[2 * DA + i];
+                    const double delta = (double)dm;
+                    t1 += (a1[i] - a2[i]) * (a2[DA + i] - a1[DA + i]);
+                    t2 += ((a1[DA + i] + a2[DA + i]) * delta) * delta;
+                }
+                dist[off + k] = 0.5 * t1 + 0.5 * t2;
+                continue;
+            }
             const double ldx = log(tmp[k]);
             tmp[k] = ldx;
             dist[off + k] = finish_distance(kind, lambdac, clu_pk[k * REC + REC - 1], clu_ld[k], nA, ldS, ldx);
@@ -2105,7 +2121,16 @@ __global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
             }
             for (int e = tid; e < REC; e += CIN_TPB) Cp[e] = Cp[e] + Sp[e];
             __syncthreads();
-            if (TWO && kind == SPKD_GLR) {
+            if (kl2) {
+                if (wave == 0) {                         // the grown cluster's KL2 vectors
+                    double a[DA];
+                    single_rows_from_qr(ldsA, a);
+                    const double nM = ldsA[QREC_COUNT_AT];
+                    const double mean_i = a[D] / nM;
+                    cov_rows(a, nM);
+                    kl2_aux_from_cov(a, mean_i, clu_aux + (long long)best * AUX);
+                }
+            } else if (TWO && kind == SPKD_GLR) {
                 if (wave == 0) {
                     const double v = quad_pair_det<TWO>(kind, ldsA, ldsA[QREC_COUNT_AT], Cx, Cx, Cp, true, L, err);
                     if (lane == 0) clu_ld[best] = log(v);
@@ -2120,6 +2145,7 @@ __global__ __launch_bounds__(CIN_TPB) void k_cluster_in(
             const double* Sp = seg_pk + s * REC;
             for (int e = tid; e < QREC; e += CIN_TPB) Cx[e] = ldsA[e];
             for (int e = tid; e < REC; e += CIN_TPB) Cp[e] = Sp[e];
+            if (kl2) for (int e = tid; e < AUX; e += CIN_TPB) clu_aux[K * AUX + e] = seg_aux[s * AUX + e];
             if (tid == 0) { clu_ld[K] = ldS; label[s] = (int32_t)K; }
         }
         off += K;

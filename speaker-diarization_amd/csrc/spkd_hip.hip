@@ -521,7 +521,7 @@ spkd_status spkd_distance_matrix(spkd_ctx* c, int kind, double lambdac, const do
 spkd_status spkd_cluster_in(spkd_ctx* c, const double* d_stats, int64_t n, int kind, double lambdac, double threshold,
                             int32_t* h_label, double* h_dist, int64_t dist_cap, int64_t* h_dist_off,
                             int64_t* h_n_done, int64_t* h_n_clusters) {
-    if (!c || n < 0 || dist_cap < 0 || (kind != SPKD_BIC && kind != SPKD_GLR)) return SPKD_EINVAL;
+    if (!c || n < 0 || dist_cap < 0 || kind < 0 || kind > 2) return SPKD_EINVAL;
     if (h_n_done) *h_n_done = 0;
     if (h_n_clusters) *h_n_clusters = 0;
     if (n == 0) return SPKD_OK;
@@ -536,13 +536,14 @@ spkd_status spkd_cluster_in(spkd_ctx* c, const double* d_stats, int64_t n, int k
     if ((st = scratch(c, S_AHC_AUX, nn * AUX * sizeof(double), &p_aux)) != SPKD_OK) return st;
     if ((st = scratch(c, S_STEP_EXM, nn * QREC * sizeof(double), &p_cex)) != SPKD_OK) return st;
     if ((st = scratch(c, S_STEP_PKM, nn * REC * sizeof(double), &p_cpk)) != SPKD_OK) return st;
-    // misc: cluster log dets | determinants of a step | dist_off | done | labels
-    const size_t misc_bytes = 2 * nn * sizeof(double) + (nn + 1 + 2) * sizeof(long long) + nn * sizeof(int32_t) + 64;
+    // misc: cluster log dets | determinants of a step | cluster KL2 vectors | dist_off | done | labels
+    const size_t misc_bytes = (2 + AUX) * nn * sizeof(double) + (nn + 1 + 2) * sizeof(long long) + nn * sizeof(int32_t) + 64;
     if ((st = scratch(c, S_STEP_MISC, misc_bytes, &p_misc)) != SPKD_OK) return st;
     if ((st = scratch(c, S_AHC_MAT, (size_t)std::max<int64_t>(dist_cap, 1) * sizeof(double), &p_dist)) != SPKD_OK) return st;
     double* clu_ld = (double*)p_misc;
     double* tmp = clu_ld + nn;
-    long long* d_off = (long long*)(tmp + nn);
+    double* clu_aux = tmp + nn;
+    long long* d_off = (long long*)(clu_aux + nn * AUX);
     long long* d_done = d_off + nn + 1;
     int32_t* d_label = (int32_t*)(d_done + 2);
     HIPCHK(c, hipMemsetAsync(d_done, 0, 2 * sizeof(long long), c->stream));
@@ -551,15 +552,24 @@ spkd_status spkd_cluster_in(spkd_ctx* c, const double* d_stats, int64_t n, int k
     {
         const int64_t per_block = 4 * PT_WAVES;
         const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+        // (the log dets also for KL2: they are what flags a covariance with infs or NaNs, which the
+        // reference's pinv refuses like its det)
         TIMED(c, SPKD_T_CLUSTER_PREP,
               hipLaunchKernelGGL(k_cluster_prep, dim3(blocks), dim3(PT_WAVES * WAVE), 0, c->stream,
-                                 (const double*)p_ex, n, kind, (double*)p_ld, (double*)p_aux, c->d_err));
+                                 (const double*)p_ex, n, kind == SPKD_KL2 ? (int)SPKD_BIC : kind, (double*)p_ld, (double*)p_aux, c->d_err));
+        if (kind == SPKD_KL2) {
+            void* p_ld2 = nullptr;                       // (the KL2 pass of the same kernel rewrites ld with zeros)
+            if ((st = scratch(c, S_AHC_OUT, nn * sizeof(double), &p_ld2)) != SPKD_OK) return st;
+            const unsigned blocks1 = (unsigned)((n + PT_WAVES - 1) / PT_WAVES);
+            hipLaunchKernelGGL(k_cluster_prep, dim3(blocks1), dim3(PT_WAVES * WAVE), 0, c->stream,
+                               (const double*)p_ex, n, (int)SPKD_KL2, (double*)p_ld2, (double*)p_aux, c->d_err);
+        }
     }
     auto kin = kind == SPKD_GLR ? k_cluster_in<true> : k_cluster_in<false>;
     (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
     hipLaunchKernelGGL(kin, dim3(1), dim3(CIN_TPB), 0, c->stream,
-                       (const double*)p_ex, d_stats, (const double*)p_ld, (long long)n, kind, lambdac, threshold,
-                       (double*)p_cex, (double*)p_cpk, clu_ld, tmp, d_label, (double*)p_dist, (long long)dist_cap,
+                       (const double*)p_ex, d_stats, (const double*)p_ld, (const double*)p_aux, (long long)n, kind, lambdac, threshold,
+                       (double*)p_cex, (double*)p_cpk, clu_ld, clu_aux, tmp, d_label, (double*)p_dist, (long long)dist_cap,
                        d_off, d_done, c->d_err);
     (void)hipEventRecord(c->kb[SPKD_T_AHC], c->stream);
     c->kused[SPKD_T_AHC] = true;

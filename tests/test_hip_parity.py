@@ -503,7 +503,7 @@ def test_cluster_in_device_chain_equals_the_per_line_path(eng, variant, tmp_path
     members' records, the decisions on the device, prints and statistics replayed on the host)
     against the same mode driven line by line (statistics of every cluster from its frames, one
     library call per line) and against the C oracle: same recipe lines, same summary, printed
-    distances to 1e-9 -- BIC and GLR, a threshold that founds a cluster per line (the distance
+    distances to 1e-9 -- BIC, GLR and KL2 (1e-4 against the oracle), a threshold that founds a cluster per line (the distance
     buffer's first guess overflows and is grown), and a NaN frame in a late line (the chain stops
     there, the per-line path raises where the reference does)."""
     from oracle.c_engine import COracleEngine
@@ -522,13 +522,21 @@ def test_cluster_in_device_chain_equals_the_per_line_path(eng, variant, tmp_path
         assert_stdout_close(a[1], b[1], rel)
 
     synth.write_fea(os.path.join(tmp, 'fea', 's.fea'), feats)
-    for extra in (['-l', '1.3', '-tt'], ['-d', 'GLR', '-t', '1800', '-tt'], ['-l', '1.3', '-t=-1e30']):
+    for extra in (['-l', '1.3', '-tt'], ['-d', 'GLR', '-t', '1800', '-tt'], ['-d', 'KL2', '-t', '12', '-tt'],
+                  ['-l', '1.3', '-t=-1e30']):
         chain = _in_mode(tmp, eng, variant, extra)
         slow = _in_mode(tmp, _NoChain(eng), variant, extra)
         orc = _in_mode(tmp, COracleEngine(), variant, extra)
         assert chain[2] is None and chain[0].count('\n') == len(lines)
-        same(chain, slow)
-        same(chain, orc)
+        # (KL2: the means enter rounded to float32, like np.mean of float32 frames; the C oracle and
+        # the library round sums of different orders, a last-bit flip of a float32 mean is 1e-7 of a
+        # delta and, squared and weighted, up to a few 1e-5 of a distance: the lines must agree, the
+        # printed distances to 1e-4; chain and per-line path share the rounding)
+        kl2 = 'KL2' in extra
+        same(chain, slow, 1e-7 if kl2 else 1e-9)
+        same(chain, orc, 1e-4 if kl2 else 1e-9)
+        if kl2:
+            assert 1 < len(set(re.findall(r'speaker=(\S+)', chain[0]))) < len(lines)
     assert len(set(re.findall(r'speaker=(\S+)', chain[0]))) == len(lines)          # the last run: a cluster per line
     bad = feats.copy()
     a, b, _ = truth[60]
