@@ -194,12 +194,25 @@ __device__ __forceinline__ void sweep_dump_packed(SPKD_GLOBAL double* rec, const
     int bi = SL.bi, bj = SL.bj;
     asm volatile("" : "+v"(bi), "+v"(bj));              // (see sweep_dump_lds)
     const int r0 = G::BR * bi, j0 = G::BC * bj;
+    // element (r0, j0 + v) sits at e0 + v (39 - j0) - v (v - 1) / 2: one multiply for the block,
+    // the columns by compile-time steps (pk_low per column is a multiply and a 64-bit add each)
+    const int c39 = (DA - 1) - j0;
+    const int e0 = pk_low(r0, j0);
     if (!SL.diag) {
 #pragma unroll
         for (int v = 0; v < G::BC; ++v) {
-            SPKD_GLOBAL double* col = rec + pk_low(r0, j0 + v);
+            SPKD_GLOBAL double* col = rec + (e0 + v * c39 - (v * (v - 1)) / 2);
 #pragma unroll
             for (int u = 0; u < G::BR; ++u) col[u] = acc[u * G::BC + v];
+        }
+    } else if constexpr (G::BR == G::BC) {
+        // a square block on the diagonal (r0 == j0): column v holds rows v .. BR - 1, contiguous
+        // from its diagonal element -- straight-line stores, no per-entry predicate
+#pragma unroll
+        for (int v = 0; v < G::BC; ++v) {
+            SPKD_GLOBAL double* col = rec + (e0 + v * c39 - (v * (v - 1)) / 2);
+#pragma unroll
+            for (int u = v; u < G::BR; ++u) col[u] = acc[u * G::BC + v];
         }
     } else {
 #pragma unroll
