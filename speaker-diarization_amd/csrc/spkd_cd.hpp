@@ -103,7 +103,10 @@ template <int NW> struct GwShape;
 template <> struct GwShape<8> { static constexpr int BR = 2, BC = 2, TILE = 128; };
 template <> struct GwShape<4> { static constexpr int BR = 2, BC = 2, TILE = 128; };
 template <> struct GwShape<2> { static constexpr int BR = 4, BC = 2, TILE = 64; };
-template <> struct GwShape<1> { static constexpr int BR = 4, BC = 4, TILE = 32; };
+#ifndef SPKD_GW1_TILE
+#define SPKD_GW1_TILE 48        // frames per LDS tile with a wave per turn (32: 15.5 KB of LDS a wave, 48: 17.6)
+#endif
+template <> struct GwShape<1> { static constexpr int BR = 4, BC = 4, TILE = SPKD_GW1_TILE; };
 
 template <int NW>
 struct Gw {
