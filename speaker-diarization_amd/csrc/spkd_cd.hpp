@@ -932,6 +932,10 @@ __global__ __launch_bounds__(Gw<NW>::TPB, NW == 8 ? 1 : 2) void k_gw(
         //        (fine scans: s_ldS still holds the pooled term of this window)
         BestD best;
         {
+            // (no contraction into FMAs in this block: k_gw is compiled once per wave shape, and the
+            // shapes must round a distance alike whatever code surrounds the formula -- a one-ulp
+            // difference between k_gw<1> and k_gw<4> showed up when the code below was changed)
+#pragma clang fp contract(off)
             const double N = (double)(c - a);
             // the window's two common terms are one thread's work (the last wave has no
             // candidates in a typical scan and runs beside the first one's logs); the others
