@@ -37,6 +37,47 @@ __device__ __forceinline__ double dkey_inv(unsigned long long k) {
     unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
+// Wave-wide integer reductions without LDS: four DPP steps inside each row of 16 lanes (min and
+// max are idempotent: quad_perm xor 1, xor 2, row_half_mirror, row_mirror leave the row's result
+// in every lane), then the four rows by v_readlane and scalar arithmetic.  The result is uniform.
+// (The selection of k_ahc_step used 64-bit __shfl_xor butterflies with fp64 compares: six
+// dependent steps of ~14 ds_bpermute each, 3.8 k cycles per wave; these take ~150.)
+template <bool MAXOP>
+__device__ __forceinline__ unsigned wave_red_u32(unsigned x) {
+    auto op = [](unsigned a, unsigned b) { return MAXOP ? (a > b ? a : b) : (a < b ? a : b); };
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));   // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0), b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32), d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+    return op(op(a, b), op(c, d));
+}
+// inclusive prefix sum over the wave: four shifts inside a row of 16 (zeros shifted in), then
+// lane 15 of rows 0 and 2 into rows 1 and 3, lane 31 into rows 2 and 3
+__device__ __forceinline__ int wave_scan_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return x;
+}
+template <bool MAXOP>
+__device__ __forceinline__ unsigned long long wave_red_u64(unsigned long long k) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned h = wave_red_u32<MAXOP>(hi);
+    const unsigned l = wave_red_u32<MAXOP>(hi == h ? lo : (MAXOP ? 0u : 0xffffffffu));
+    return ((unsigned long long)h << 32) | l;
+}
+// the smallest (key, idx) pair of the wave, lexicographically
+__device__ __forceinline__ void wave_argmin_key(unsigned long long key, unsigned idx,
+                                                unsigned long long& okey, unsigned& oidx) {
+    okey = wave_red_u64<false>(key);
+    oidx = wave_red_u32<false>(key == okey ? idx : 0xffffffffu);
+}
+
 __device__ __forceinline__ bool stat_valid(double d) {       // "d != inf and d != -inf", NaN never updates
     return d == d && fabs(d) < __builtin_huge_val();
 }
@@ -647,12 +688,14 @@ __device__ __forceinline__ void refresh_rows(const double* __restrict__ Dm, long
                     if (v[u] < mv || (v[u] == mv && c < mc)) { mv = v[u]; mc = c; }
                 }
             }
-#pragma unroll
-            for (int s = 1; s < WAVE; s <<= 1) {
-                const double v2 = __shfl_xor(mv, s);
-                const int c2 = __shfl_xor(mc, s), n2 = __shfl_xor(nc, s);
-                if (v2 < mv || (v2 == mv && c2 < mc)) { mv = v2; mc = c2; }
-                nc = n2 < nc ? n2 : nc;
+            {
+                // (the wave's minimum and its first column in integers: DPP row steps + v_readlane)
+                unsigned long long okey;
+                unsigned oc;
+                wave_argmin_key(mc != NO_COL ? dkey(mv) : ~0ull, (unsigned)mc, okey, oc);
+                mv = okey != ~0ull ? dkey_inv(okey) : __builtin_huge_val();
+                mc = okey != ~0ull ? (int)oc : NO_COL;
+                nc = __any(nc != NO_COL) ? (int)wave_red_u32<false>((unsigned)nc) : NO_COL;
             }
             if (lane == 0) { rmin[r] = mv; rarg[r] = mc; rnan[r] = nc; dirty[r] = 0; }
 #ifdef SPKD_PROFILE
@@ -675,9 +718,8 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         double* __restrict__ final_max, double* __restrict__ final_min, int* err) {
     extern __shared__ int32_t ids[];                    // alive partner slots of the merged cluster
     __shared__ double ldsA[QREC];
-    __shared__ ArgMin red[AHC_WAVES];
+    __shared__ unsigned long long red3[AHC_WAVES][3];
     __shared__ unsigned long long s_masks[AHC_MAX_N / WAVE];
-    __shared__ ArgMin best;
     __shared__ int s_cnt[2];
     __shared__ int s_nids;
     __shared__ double s_tmax[AHC_WAVES];
@@ -714,35 +756,39 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         // ---- 1. min / argmin over the alive sub-matrix, numpy semantics: first
         // occurrence in row-major order; any NaN -> min is NaN and argmin the first
         // NaN (distances.min(), distances.argmin(): CL1:203-204)
-        ArgMin mine;
-        mine.v = __builtin_huge_val(); mine.idx = INF_IDX; mine.nan_idx = INF_IDX;
+        // in integers, like the selection of the step chain below: a distance by its order-
+        // preserving key, a thread meets its rows in ascending order (a strict "<" keeps the first
+        // of equal keys), wave reductions by DPP row steps + v_readlane (wave_red_u64), every
+        // thread folds the eight waves' results for itself -- no second barrier
+        unsigned long long kb = ~0ull, ib = ~0ull, inan = ~0ull;
         for (long long r = tid; r < N; r += AHC_TPB) {
             if (!al[r]) continue;
             const double v = rmin[r];
             const int c = rarg[r], nc = rnan[r];
-            if (nc != NO_COL) { const long long l = r * N + nc; if (l < mine.nan_idx) mine.nan_idx = l; }
+            if (nc != NO_COL) { const unsigned long long l = (unsigned long long)(r * N + nc); inan = l < inan ? l : inan; }
             if (c != NO_COL) {
-                const long long l = r * N + c;
-                if (v < mine.v || (v == mine.v && l < mine.idx)) { mine.v = v; mine.idx = l; }
+                const unsigned long long kv = dkey(v);
+                if (kv < kb) { kb = kv; ib = (unsigned long long)(r * N + c); }
             }
         }
+        {
+            const unsigned long long wk = wave_red_u64<false>(kb);
+            const unsigned long long wi = wave_red_u64<false>(kb == wk ? ib : ~0ull);
+            const unsigned long long wn = __any(inan != ~0ull) ? wave_red_u64<false>(inan) : ~0ull;
+            if (lane == 0) { red3[wave][0] = wk; red3[wave][1] = wi; red3[wave][2] = wn; }
+        }
+        __syncthreads();
+        unsigned long long bk = red3[0][0], bi = red3[0][1], bn = red3[0][2];
 #pragma unroll
-        for (int s = 1; s < WAVE; s <<= 1) {
-            ArgMin o;
-            o.v = __shfl_xor(mine.v, s); o.idx = __shfl_xor(mine.idx, s); o.nan_idx = __shfl_xor(mine.nan_idx, s);
-            argmin_merge(mine, o);
+        for (int w = 1; w < AHC_WAVES; ++w) {
+            const unsigned long long ok = red3[w][0], oi = red3[w][1], on = red3[w][2];
+            const bool t = ok < bk || (ok == bk && oi < bi);
+            bk = t ? ok : bk; bi = t ? oi : bi;
+            bn = on < bn ? on : bn;
         }
-        if (lane == 0) red[wave] = mine;
-        __syncthreads();
-        if (tid == 0) {
-            ArgMin b = red[0];
-            for (int w = 1; w < AHC_WAVES; ++w) argmin_merge(b, red[w]);
-            best = b;
-        }
-        __syncthreads();
-        const bool has_nan = best.nan_idx != INF_IDX;
-        const double mind = has_nan ? __builtin_nan("") : best.v;
-        const long long index = has_nan ? best.nan_idx : best.idx;
+        const bool has_nan = bn != ~0ull;
+        const double mind = has_nan ? __builtin_nan("") : (bi != ~0ull ? dkey_inv(bk) : __builtin_huge_val());
+        const long long index = has_nan ? (long long)bn : (bi != ~0ull ? (long long)bi : INF_IDX);
         fmin = mind;
         const bool go = (mind <= threshold) || (max_spk > 0 && m > max_spk);
         if (!go) break;
@@ -762,8 +808,9 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
             for (long long c = tid; c < sb; c += AHC_TPB) {
                 if (al[c]) { cb++; if (c < sa) ca++; }
             }
-#pragma unroll
-            for (int s = 1; s < WAVE; s <<= 1) { ca += __shfl_xor(ca, s); cb += __shfl_xor(cb, s); }
+            // (wave sums by a DPP prefix scan: the total sits in lane 63)
+            ca = __builtin_amdgcn_readlane(wave_scan_i32(ca), WAVE - 1);
+            cb = __builtin_amdgcn_readlane(wave_scan_i32(cb), WAVE - 1);
             if (lane == 0 && ca) atomicAdd(&s_cnt[0], ca);
             if (lane == 0 && cb) atomicAdd(&s_cnt[1], cb);
         }
@@ -875,15 +922,11 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         }
         if (tid == 0) dirty[sa] = 1;
         if (variant == 1) {
-#pragma unroll
-            for (int s = 1; s < WAVE; s <<= 1) {
-                const double x = __shfl_xor(wmax, s), n2 = __shfl_xor(wmin, s);
-                if (x == x && (wmax != wmax || x > wmax)) wmax = x;
-                if (n2 == n2 && (wmin != wmin || n2 < wmin)) wmin = n2;
-            }
+            const unsigned long long kmax = wave_red_u64<true>(wmax == wmax ? dkey(wmax) : 0ull);
+            const unsigned long long kmin = wave_red_u64<false>(wmin == wmin ? dkey(wmin) : ~0ull);
             if (lane == 0) {
-                if (wmax == wmax) atomicMax(stat_max + p, dkey(wmax));
-                if (wmin == wmin) atomicMin(stat_min + p, dkey(wmin));
+                if (kmax != 0ull) atomicMax(stat_max + p, kmax);
+                if (kmin != ~0ull) atomicMin(stat_min + p, kmin);
             }
         }
         __syncthreads();
@@ -1420,47 +1463,6 @@ constexpr int STEP_PARTNERS = 4 * STEP_WAVES - 1;          // + the merged clust
 constexpr int ALIVE_ROUND = 0x7fffffff;
 constexpr int STEP_MAX_N = 16384;                          // (two int arrays of N in LDS; positions packed as row << 14 | column)
 constexpr int STEP_IDX_SHIFT = 14;
-
-// Wave-wide integer reductions without LDS: four DPP steps inside each row of 16 lanes (min and
-// max are idempotent: quad_perm xor 1, xor 2, row_half_mirror, row_mirror leave the row's result
-// in every lane), then the four rows by v_readlane and scalar arithmetic.  The result is uniform.
-// (The selection of k_ahc_step used 64-bit __shfl_xor butterflies with fp64 compares: six
-// dependent steps of ~14 ds_bpermute each, 3.8 k cycles per wave; these take ~150.)
-template <bool MAXOP>
-__device__ __forceinline__ unsigned wave_red_u32(unsigned x) {
-    auto op = [](unsigned a, unsigned b) { return MAXOP ? (a > b ? a : b) : (a < b ? a : b); };
-    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));   // row_half_mirror
-    x = op(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));   // row_mirror
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0), b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32), d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
-    return op(op(a, b), op(c, d));
-}
-// inclusive prefix sum over the wave: four shifts inside a row of 16 (zeros shifted in), then
-// lane 15 of rows 0 and 2 into rows 1 and 3, lane 31 into rows 2 and 3
-__device__ __forceinline__ int wave_scan_i32(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
-    return x;
-}
-template <bool MAXOP>
-__device__ __forceinline__ unsigned long long wave_red_u64(unsigned long long k) {
-    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
-    const unsigned h = wave_red_u32<MAXOP>(hi);
-    const unsigned l = wave_red_u32<MAXOP>(hi == h ? lo : (MAXOP ? 0u : 0xffffffffu));
-    return ((unsigned long long)h << 32) | l;
-}
-// the smallest (key, idx) pair of the wave, lexicographically
-__device__ __forceinline__ void wave_argmin_key(unsigned long long key, unsigned idx,
-                                                unsigned long long& okey, unsigned& oidx) {
-    okey = wave_red_u64<false>(key);
-    oidx = wave_red_u32<false>(key == okey ? idx : 0xffffffffu);
-}
 
 struct StepState {
     int32_t done, n_merges;
