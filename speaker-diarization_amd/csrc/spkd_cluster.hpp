@@ -722,6 +722,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
     __shared__ unsigned long long s_masks[AHC_MAX_N / WAVE];
     __shared__ int s_cnt[2];
     __shared__ int s_nids;
+    __shared__ int s_next;                              // next quad of partners of the running merge
     __shared__ double s_tmax[AHC_WAVES];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const QuadLane L = quad_lane();
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         const long long sa = r0 < c0 ? r0 : c0, sb = r0 < c0 ? c0 : r0;
         // compacted indices = number of alive slots in front
         if (tid < 2) s_cnt[tid] = 0;
-        if (tid == 0) s_nids = 1;
+        if (tid == 0) { s_nids = 1; s_next = 0; }
         __syncthreads();
         {
             int ca = 0, cb = 0;
@@ -865,7 +866,13 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
                 kl2_aux_from_cov(a, mean_i, aux + (off + sa) * AUX);
             }
         } else {
-            for (int base = 4 * wave; base < nids; base += 4 * AHC_WAVES) {
+            // (the waves take the quads of partners from a counter, not by stride: a wave whose
+            // records come late takes fewer, nobody idles at the barrier for the slowest's sixth pass)
+            for (;;) {
+                int q4 = 0;
+                if (lane == 0) q4 = atomicAdd(&s_next, 1);
+                const int base = 4 * __builtin_amdgcn_readfirstlane(q4);
+                if (base >= nids) break;
                 int k = base + L.m;
                 const bool valid = k < nids;
                 k = valid ? k : nids - 1;
