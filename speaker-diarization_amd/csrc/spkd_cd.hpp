@@ -682,6 +682,7 @@ struct GwState {
     long long best_k, F, base, count;
     long long seg_src, seg_dst;    // fused mode: cache slot -> output record of the detection just made
     int nw, nd;
+    int next_q;            // several waves per turn: the next quad of items of the running scan
     int fine;              // kind of the scan about to run
     int go;                // the outer loop continues (written in the decision step only)
     int abort;             // a capacity ran out while the scan was being set up
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(Gw<NW>::TPB, NW == 8 ? 1 : 2) void k_gw(
                 }
             }
         }
+        if (tid == 0) S.next_q = 0;
         __syncthreads();
         if (S.abort) break;                  // (written before the barrier, never reset)
         // ---- (B) the sweep: P(b_k) for the new candidates, then P(c); fine: P at the F
@@ -895,7 +897,15 @@ __global__ __launch_bounds__(Gw<NW>::TPB, NW == 8 ? 1 : 2) void k_gw(
 #ifdef SPKD_PROFILE
             prof_items += (unsigned long long)M;
 #endif
-            for (long long q4 = wave; 4 * q4 < M; q4 += GW_WAVES) {
+            // (with several waves per turn they take the quads of items from a counter, not by
+            // stride: a wave whose records come late takes fewer -- as in k_ahc)
+            for (long long q4 = wave;; q4 += GW_WAVES) {
+                if constexpr (NW > 1) {
+                    int qn = 0;
+                    if (lane == 0) qn = atomicAdd(&S.next_q, 1);
+                    q4 = __builtin_amdgcn_readfirstlane(qn);
+                }
+                if (4 * q4 >= M) break;
 #ifdef SPKD_PROFILE
                 ++prof_passes;
 #endif
