@@ -830,15 +830,34 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc(
         // ---- 2. merge the statistics (speakers[a].extend(speakers[b]))
         double* A = ex + (off + sa) * QREC;
         const double* B = ex + (off + sb) * QREC;
-        for (int e = tid; e < QREC; e += AHC_TPB) {
-            const double v = A[e] + B[e];
-            A[e] = v;
-            ldsA[e] = v;
-        }
-        {                                             // the packed copies the pair passes load from
-            double* Ap = pk + (off + sa) * REC;
+        {
+            // both forms of both records asked for before the first sum is stored (A and B alias as
+            // far as the compiler knows: written as two loops they are two trips to memory in a row)
+            double* Ap = pk + (off + sa) * REC;       // the packed copies the pair passes load from
             const double* Bp = pk + (off + sb) * REC;
-            for (int e = tid; e < REC; e += AHC_TPB) Ap[e] = Ap[e] + Bp[e];
+            constexpr int NQ = (QREC + AHC_TPB - 1) / AHC_TPB, NP = (REC + AHC_TPB - 1) / AHC_TPB;
+            double qa[NQ], qb[NQ], pa[NP], pb[NP];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int e = tid + u * AHC_TPB;
+                qa[u] = A[e < QREC ? e : 0]; qb[u] = B[e < QREC ? e : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int e = tid + u * AHC_TPB;
+                pa[u] = Ap[e < REC ? e : 0]; pb[u] = Bp[e < REC ? e : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int e = tid + u * AHC_TPB;
+                const double v = qa[u] + qb[u];
+                if (e < QREC) { A[e] = v; ldsA[e] = v; }
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int e = tid + u * AHC_TPB;
+                if (e < REC) Ap[e] = pa[u] + pb[u];
+            }
         }
         __syncthreads();
         // partner list (order is irrelevant: results are scattered by slot); one LDS atomic
