@@ -1602,7 +1602,7 @@ __device__ __forceinline__ void step_scan_row(const double* __restrict__ row, lo
 // 156 VGPRs); with SW = 8 four more share the selection, the partner list and the rescans, which
 // are issue-bound per wave (15 clusters per thread at N = 3 860 with four waves) and idle at the
 // barriers through the pass.
-template <bool TWO, int SW>
+template <bool TWO, int SW, int SP>
 __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
         int k, const int64_t* __restrict__ seg_off, int variant, int kind, int max_spk, double lambdac,
         double threshold, double* __restrict__ ld, double* __restrict__ aux,
@@ -1654,7 +1654,11 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
     const long long psa = S.psa;
     const long long m = N - n_merges;                // clusters alive now
     const int n_part = (int)(m - 2);                 // partners of this merge, if it happens
-    const int nb = n_part > 0 ? (n_part + STEP_PARTNERS - 1) / STEP_PARTNERS : 1;
+    constexpr int sp = SP;
+    // SP partners per workgroup (+ the merged cluster itself): 15 = all four waves pass; 7 = two
+    // of them, when the chip has CUs to spare -- a workgroup's record loads go through one CU's
+    // address unit (41 KB a wave), so half the passes per CU are back in half the time
+    const int nb = n_part > 0 ? (n_part + sp - 1) / sp : 1;
     // workgroups 0 .. nb - 1 take the partners; workgroup nb is the BOOKKEEPER: it selects like
     // everybody, forms the merged record, and writes it out (both layouts), the slot word, the
     // count, the death mark and the merge log while the others eliminate -- 5 k cycles that sat
@@ -1905,8 +1909,8 @@ __global__ __launch_bounds__(SW * WAVE) void k_ahc_step(
     STEP_TICK(4);
     // ---- P. this workgroup's items: item 0 = the merged cluster itself, item j >= 1 = partner
     // s_ids[first + j - 1]
-    const int first = (int)blockIdx.x * STEP_PARTNERS;
-    const int mine_n = n_part - first < STEP_PARTNERS ? n_part - first : STEP_PARTNERS;   // partners here (>= 0)
+    const int first = (int)blockIdx.x * sp;
+    const int mine_n = n_part - first < sp ? n_part - first : sp;   // partners here (>= 0)
     // what the finish needs of a partner (its count, its log term, its row cache), asked for now:
     // the answers arrive under the pass
     const bool fin = tid >= 1 && tid <= mine_n;

@@ -32,6 +32,7 @@ struct spkd_ctx {
     int gw_waves = 0;
     unsigned long long init_keys[2] = {0ull, ~0ull};
     int step_waves = 0;          // step chain: waves per workgroup (0 = by problem size, 4, 8)
+    int step_partners = 0;       // step chain: partners per workgroup (0 = by problem size, 3, 7, 15)
     int ahc_chain = 0;           // wide merge loop: 0 / 2 = the step chain (no hand-offs), 1 = the ticket chain
     int64_t last_gw_items = 0;
     std::string err;
@@ -178,6 +179,7 @@ static spkd_status create_ctx(int device, void* stream, bool borrow, spkd_ctx** 
     if (const char* e = getenv("SPKD_GW_WAVES")) c->gw_waves = atoi(e);
     if (const char* e = getenv("SPKD_AHC_CHAIN")) c->ahc_chain = atoi(e);
     if (const char* e = getenv("SPKD_STEP_WAVES")) { const int v = atoi(e); c->step_waves = (v == 4 || v == 8) ? v : 0; }
+    if (const char* e = getenv("SPKD_STEP_PARTNERS")) { const int v = atoi(e); c->step_partners = (v == 3 || v == 7 || v == 15) ? v : 0; }
     *out = c;
     return SPKD_OK;
 }
@@ -695,8 +697,16 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         // eight waves per workgroup once a thread of four would meet more than ~4 clusters in the
         // selection (SPKD_STEP_WAVES = 4 | 8 overrides; results do not depend on it)
         const int step_waves = c->step_waves ? c->step_waves : (n_max > STEP_WIDE_FROM ? 8 : 4);
-        auto kstep = step_waves == 8 ? (P->kind == SPKD_GLR ? k_ahc_step<true, 8> : k_ahc_step<false, 8>)
-                                     : (P->kind == SPKD_GLR ? k_ahc_step<true, 4> : k_ahc_step<false, 4>);
+        // partners per workgroup: seven (two of the four waves pass) while that leaves every workgroup a CU
+        // of its own, else fifteen (SPKD_STEP_PARTNERS = 7 | 15 overrides; four-wave workgroups only)
+        const bool glr_k = P->kind == SPKD_GLR;
+        const int step_sp = step_waves == 8 ? STEP_PARTNERS
+                            : (c->step_partners ? c->step_partners
+                               : ((n_max * n_prob <= 3 * 256) ? 3 : ((n_max * n_prob <= 7 * 256) ? 7 : STEP_PARTNERS)));
+        auto kstep = step_waves == 8 ? (glr_k ? k_ahc_step<true, 8, STEP_PARTNERS> : k_ahc_step<false, 8, STEP_PARTNERS>)
+                     : step_sp == 3  ? (glr_k ? k_ahc_step<true, 4, 3> : k_ahc_step<false, 4, 3>)
+                     : step_sp == 7  ? (glr_k ? k_ahc_step<true, 4, 7> : k_ahc_step<false, 4, 7>)
+                                     : (glr_k ? k_ahc_step<true, 4, STEP_PARTNERS> : k_ahc_step<false, 4, STEP_PARTNERS>);
         const size_t nch_max = (size_t)((n_max + WAVE - 1) / WAVE);
         const size_t step_lds = ((size_t)2 * n_max + nch_max + 2) * sizeof(int32_t) + nch_max * sizeof(unsigned long long);
         if (step_lds + 20 * 1024 > 48 * 1024)
@@ -708,7 +718,7 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         for (int64_t it = 1; it < n_max; ++it) {
             const int64_t partners = n_max - it - 1;
             // (+ 1: the bookkeeper workgroup of every problem)
-            const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + STEP_PARTNERS - 1) / STEP_PARTNERS) + 1;
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + step_sp - 1) / step_sp) + 1;
             hipLaunchKernelGGL(kstep, dim3(blocks, (unsigned)n_prob), dim3(step_waves * WAVE), step_lds, c->stream,
                                (int)it, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
                                P->threshold, B.ld, B.aux, B.mat, (const int64_t*)B.mat_off, Q, d_a, d_b, d_merge_d,

@@ -579,3 +579,34 @@ def test_tiny_problems_through_every_chain(eng, kind):
         label, dists, done = eng.cluster_in(segs, kind, 1.3, thr)
         assert done == n and len(label) == n and int(label[0]) == 0
         assert [len(d) for d in dists] == [0] + [len(set(int(x) for x in label[:s])) for s in range(1, n)]
+
+
+@pytest.mark.parametrize('kind', ['BIC', 'GLR'])
+def test_step_chain_shapes_agree(kind, monkeypatch):
+    """The hand-off-free merge chain deals a merge's partners 3, 7 or 15 to a workgroup (by the
+    problem's size: a workgroup's record loads go through one CU's address unit, so with CUs to
+    spare fewer partners per workgroup are back sooner) and runs four or eight waves a workgroup:
+    same merges, same distances to the bit, same statistics whatever the shape."""
+    synth = pkg('synth')
+    hipabi = pkg('hipabi')
+    engine = pkg('engine')
+    feats, _, truth = synth.make_session(4243, 600, 4)
+    segs = [(a, b) for a, b, _ in truth]
+    thr = {'BIC': 0.0, 'GLR': 2500.0}[kind]
+    got = []
+    for sp, sw in ((3, 4), (7, 4), (15, 4), (15, 8)):
+        monkeypatch.setenv('SPKD_STEP_PARTNERS', str(sp))
+        monkeypatch.setenv('SPKD_STEP_WAVES', str(sw))
+        e = engine.HipEngine(0)                       # (the switches are read when the context is made)
+        try:
+            e.set_features(feats)
+            e.ahc_path = hipabi.AHC_WIDE
+            got.append([e.cluster_hi(segs, v, kind, 1.3, thr, ms) for v in (1, 2) for ms in (0, 3)])
+        finally:
+            e.close()
+    assert len(got[0][0].merges) > 20
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert [(x, y) for x, y, _ in a.merges] == [(x, y) for x, y, _ in b.merges]
+            assert all(d1 == d2 or (math.isnan(d1) and math.isnan(d2)) for (_, _, d1), (_, _, d2) in zip(a.merges, b.merges))
+            assert (a.max_dist, a.min_dist) == (b.max_dist, b.min_dist) or (a.max_dist != a.max_dist)
