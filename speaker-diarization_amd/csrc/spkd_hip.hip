@@ -699,18 +699,34 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         const int step_waves = c->step_waves ? c->step_waves : (n_max > STEP_WIDE_FROM ? 8 : 4);
         // partners per workgroup: seven (two of the four waves pass) while that leaves every workgroup a CU
         // of its own, else fifteen (SPKD_STEP_PARTNERS = 7 | 15 overrides; four-wave workgroups only)
+        // partners of a merge per workgroup -- 3, 7 or 15: one, two or four of a workgroup's waves
+        // eliminate -- chosen PER ROUND from the partners that are left, so that every workgroup
+        // has a CU to itself while the chip has CUs to spare (a workgroup's record loads go through
+        // one CU's address unit); SPKD_STEP_PARTNERS = 3 | 7 | 15 pins it
         const bool glr_k = P->kind == SPKD_GLR;
-        const int step_sp = step_waves == 8 ? STEP_PARTNERS
-                            : (c->step_partners ? c->step_partners
-                               : ((n_max * n_prob <= 3 * 256) ? 3 : ((n_max * n_prob <= 7 * 256) ? 7 : STEP_PARTNERS)));
-        auto kstep = step_waves == 8 ? (glr_k ? k_ahc_step<true, 8, STEP_PARTNERS> : k_ahc_step<false, 8, STEP_PARTNERS>)
-                     : step_sp == 3  ? (glr_k ? k_ahc_step<true, 4, 3> : k_ahc_step<false, 4, 3>)
-                     : step_sp == 7  ? (glr_k ? k_ahc_step<true, 4, 7> : k_ahc_step<false, 4, 7>)
-                                     : (glr_k ? k_ahc_step<true, 4, STEP_PARTNERS> : k_ahc_step<false, 4, STEP_PARTNERS>);
+        using StepKernel = decltype(&k_ahc_step<false, 4, 3>);
+        StepKernel kvar[3];                              // [0] 3, [1] 7, [2] 15 partners
+        if (step_waves == 8) {
+            kvar[0] = glr_k ? k_ahc_step<true, 8, 3> : k_ahc_step<false, 8, 3>;
+            kvar[1] = glr_k ? k_ahc_step<true, 8, 7> : k_ahc_step<false, 8, 7>;
+            kvar[2] = glr_k ? k_ahc_step<true, 8, STEP_PARTNERS> : k_ahc_step<false, 8, STEP_PARTNERS>;
+        } else {
+            kvar[0] = glr_k ? k_ahc_step<true, 4, 3> : k_ahc_step<false, 4, 3>;
+            kvar[1] = glr_k ? k_ahc_step<true, 4, 7> : k_ahc_step<false, 4, 7>;
+            kvar[2] = glr_k ? k_ahc_step<true, 4, STEP_PARTNERS> : k_ahc_step<false, 4, STEP_PARTNERS>;
+        }
+        auto sp_of_round = [&](int64_t partners) -> int {
+            if (c->step_partners) return c->step_partners;
+            const int64_t free_cus = 255;                // (the bookkeeper takes one)
+            if (partners * n_prob <= 3 * free_cus) return 3;
+            if (partners * n_prob <= 7 * free_cus) return 7;
+            return STEP_PARTNERS;
+        };
         const size_t nch_max = (size_t)((n_max + WAVE - 1) / WAVE);
         const size_t step_lds = ((size_t)2 * n_max + nch_max + 2) * sizeof(int32_t) + nch_max * sizeof(unsigned long long);
         if (step_lds + 20 * 1024 > 48 * 1024)
-            (void)hipFuncSetAttribute((const void*)kstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
+            for (int v = 0; v < 3; ++v)
+                (void)hipFuncSetAttribute((const void*)kvar[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds);
         (void)hipEventRecord(c->ka[SPKD_T_AHC], c->stream);
         const unsigned row_blocks = (unsigned)((n_max + AHC_WAVES - 1) / AHC_WAVES);
         hipLaunchKernelGGL(k_step_init, dim3(row_blocks, (unsigned)n_prob), dim3(AHC_TPB), 0, c->stream,
@@ -718,6 +734,8 @@ spkd_status ahc_impl(spkd_ctx* c, const double* d_stats, const int64_t* h_seg_of
         for (int64_t it = 1; it < n_max; ++it) {
             const int64_t partners = n_max - it - 1;
             // (+ 1: the bookkeeper workgroup of every problem)
+            const int step_sp = sp_of_round(partners);
+            StepKernel kstep = kvar[step_sp == 3 ? 0 : (step_sp == 7 ? 1 : 2)];
             const unsigned blocks = (unsigned)std::max<int64_t>(1, (partners + step_sp - 1) / step_sp) + 1;
             hipLaunchKernelGGL(kstep, dim3(blocks, (unsigned)n_prob), dim3(step_waves * WAVE), step_lds, c->stream,
                                (int)it, (const int64_t*)B.seg_off, P->variant, P->kind, P->max_spk, P->lambdac,
