@@ -1480,7 +1480,8 @@ __global__ __launch_bounds__(AHC_TPB) void k_ahc_final(
 //     word (round | new | old) that reads correctly before and after workgroup 0 replaces it.
 // Against the ticket form (k_ahc_round: release fence, ticket, acquire fence, then one
 // workgroup selects while the others have left) a merge loses ~4 us of fences and atomics and
-// three dependent passes of the last arriver: 25.5 -> ~16 us per merge at N = 380.
+// three dependent passes of the last arriver: 25.5 -> 14 us per merge at N = 380 (with the
+// selection in integers, the bookkeeper workgroup and three partners a workgroup, below).
 // Arithmetic, tie-breaks and NaN rules are those of k_ahc; results are bit-identical.
 // ---------------------------------------------------------------------------
 constexpr int STEP_WAVES = 4;
@@ -1597,7 +1598,8 @@ __device__ __forceinline__ void step_scan_row(const double* __restrict__ row, lo
 }
 
 // round k (k = 1 .. n_max - 1): merge k of every problem that has not stopped.
-// grid (max(1, ceil((n_max - k - 1) / STEP_PARTNERS)), n_prob); dynamic LDS: 2 N_max ints.
+// grid (max(1, ceil((n_max - k - 1) / SP)) + 1, n_prob); dynamic LDS: 2 N_max ints + the chunk masks.
+// SP partners of the merge per workgroup (3, 7 or 15: the host picks per round).
 // SW waves per workgroup: the first STEP_WAVES of them eliminate (one wave per SIMD, the pass needs
 // 156 VGPRs); with SW = 8 four more share the selection, the partner list and the rescans, which
 // are issue-bound per wave (15 clusters per thread at N = 3 860 with four waves) and idle at the
